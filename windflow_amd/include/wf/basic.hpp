@@ -1,0 +1,116 @@
+// Basic definitions shared by the whole library: enums, defaults, time helpers,
+// window-operator configuration.  Public names follow the reference's API
+// (/root/reference/wf/basic.hpp:46-274) so user code keeps compiling; the
+// implementation is new.
+#pragma once
+#include <chrono>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <tuple>
+#include <type_traits>
+
+namespace wf {
+
+// ---- time helpers (reference: basic.hpp:55-74) ----------------------------
+inline uint64_t current_time_usecs() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+inline uint64_t current_time_nsecs() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+// ---- defaults (reference: basic.hpp:77-83) --------------------------------
+constexpr size_t DEFAULT_VECTOR_CAPACITY = 500;
+constexpr size_t DEFAULT_BATCH_SIZE_TB = 1000;
+// wave64 hardware: 256 threads = 4 waves, one per SIMD of a CU
+constexpr size_t DEFAULT_GPU_THREADS_PER_BLOCK = 256;
+
+// ---- enums (reference: basic.hpp:86-132) ----------------------------------
+enum class Mode { DEFAULT, DETERMINISTIC };
+enum win_type_t { CB, TB };
+enum opt_level_t { LEVEL0, LEVEL1, LEVEL2 };
+enum routing_modes_t { NONE, FORWARD, KEYBY, COMPLEX };
+enum pattern_t { SEQ_CPU, SEQ_GPU, KF_CPU, KF_GPU, KFF_CPU, KFF_GPU, WF_CPU, WF_GPU, PF_CPU, PF_GPU, WMR_CPU, WMR_GPU };
+enum win_event_t { OLD, IN, DELAYED, FIRED, BATCHED };
+enum ordering_mode_t { ID, TS, TS_RENUMBERING };
+enum role_t { SEQ, PLQ, WLQ, MAP, REDUCE };
+
+// ---- ANSI colours (reference: basic.hpp:135-151) --------------------------
+#define WF_DEFAULT_COLOR "\033[0m"
+#define WF_RED "\033[1;31m"
+#define WF_GREEN "\033[1;32m"
+#define WF_YELLOW "\033[1;33m"
+#define WF_BLUE "\033[1;34m"
+
+// configuration error: the reference prints and exit()s; we do
+// the same by default but go through one function so tests can intercept it.
+[[noreturn]] inline void fatal_error(const std::string& msg) {
+    std::cerr << WF_RED << "WindFlow Error: " << msg << WF_DEFAULT_COLOR << std::endl;
+    std::exit(EXIT_FAILURE);
+}
+
+// Position of a window replica inside (possibly nested) window-parallel
+// operators; drives the window-assignment arithmetic of SURVEY.md A.4
+// (reference: basic.hpp:154-184).
+struct WinOperatorConfig {
+    size_t id_outer = 0;
+    size_t n_outer = 1;
+    uint64_t slide_outer = 0;
+    size_t id_inner = 0;
+    size_t n_inner = 1;
+    uint64_t slide_inner = 0;
+    WinOperatorConfig() = default;
+    WinOperatorConfig(size_t io, size_t no, uint64_t so, size_t ii, size_t ni, uint64_t si)
+        : id_outer(io), n_outer(no), slide_outer(so), id_inner(ii), n_inner(ni), slide_inner(si) {}
+};
+
+// ---- tuple contract helpers -----------------------------------------------
+// User tuples expose tuple<key_t, uint64_t id, uint64_t ts> getControlFields()
+// and setControlFields(key, id, ts) (SURVEY.md §2.1 "Tuple contract").
+template <typename T>
+using key_of_t = typename std::remove_cv<typename std::remove_reference<decltype(std::get<0>(
+    std::declval<const T&>().getControlFields()))>::type>::type;
+
+template <typename T>
+inline key_of_t<T> key_of(const T& t) {
+    return std::get<0>(t.getControlFields());
+}
+template <typename T>
+inline uint64_t id_of(const T& t) {
+    return std::get<1>(t.getControlFields());
+}
+template <typename T>
+inline uint64_t ts_of(const T& t) {
+    return std::get<2>(t.getControlFields());
+}
+template <typename T>
+inline size_t hash_of(const T& t) {
+    return std::hash<key_of_t<T>>()(key_of(t));
+}
+
+// ---- message tagging -------------------------------------------------------
+// Messages between nodes are heap pointers to tuples owned by the receiver.
+// Window operators additionally need "end-of-stream markers": a copy of the last
+// tuple of a key that only advances window state.  The reference
+// wraps such tuples in a ref-counted envelope (meta.hpp:769-872); we tag bit 0 of
+// the pointer instead (operator new returns >= 8-byte aligned storage).
+template <typename T>
+inline void* tag_marker(T* p) {
+    return reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(p) | uintptr_t(1));
+}
+inline bool is_marker(const void* p) { return (reinterpret_cast<uintptr_t>(p) & uintptr_t(1)) != 0; }
+template <typename T>
+inline T* untag(void* p) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(1));
+}
+
+}  // namespace wf

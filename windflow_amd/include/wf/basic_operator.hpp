@@ -1,0 +1,94 @@
+// Basic_Operator + StageSpec: the contract between operators and the MultiPipe.
+//
+// In the reference every operator *is* a FastFlow farm/pipeline/a2a and the
+// MultiPipe has one hand-written add()/chain() overload per operator type with
+// the emitter/ordering/collector combination spelled out
+// (/root/reference/wf/pipegraph.hpp:1565-2990, wf/basic_operator.hpp:47-79).
+// Here an operator only *describes* itself as an ordered list of stages; a stage
+// says: these are my replica nodes, this is how to build an emitter that routes
+// into them, and this is the ordering node I need in front of each replica for a
+// given execution mode.  The MultiPipe has exactly one generic wiring routine.
+#pragma once
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+#include "basic.hpp"
+#include "rt/graph.hpp"
+#include "stats_record.hpp"
+
+namespace wf {
+
+// (node, port) of an emitter that must be connected to destination replica `dest`
+struct EmitterLeaf {
+    size_t dest;
+    rt::Node* node;
+    size_t port;
+};
+// An emitter is a small tree of nodes fused in the producer's thread.  `root`
+// receives the producer's output; `leaves` are the open ports, flattened
+// (this is what the reference's Tree_Emitter does by summing getNDestinations(),
+// wf/tree_emitter.hpp:119-144).
+struct EmitterAssembly {
+    rt::Node* root = nullptr;
+    std::vector<EmitterLeaf> leaves;
+};
+
+struct StageSpec {
+    std::string name;
+    routing_modes_t routing = FORWARD;
+    std::vector<rt::Node*> replicas;  // already adopted by the graph
+    // build (and adopt into the graph) the emitter used by upstream producer
+    // `src_idx` (index of the replica of the previous stage when `internal`, else
+    // the index of the upstream endpoint)
+    std::function<EmitterAssembly(rt::Graph&, size_t src_idx)> make_emitter;
+    // ordering node to put in front of each replica for this mode (nullptr: none)
+    std::function<rt::Node*(Mode)> make_ordering;
+    bool internal = false;  // fed by the previous stage of the same operator
+};
+
+// where replicas deposit their statistics at svc_end (shared with the operator)
+struct StatsHub {
+    std::mutex m;
+    std::vector<Stats_Record> recs;
+    void add(const Stats_Record& r) {
+        std::lock_guard<std::mutex> l(m);
+        recs.push_back(r);
+    }
+};
+
+class Basic_Operator {
+public:
+    virtual ~Basic_Operator() = default;
+    virtual std::string getName() const = 0;
+    virtual size_t getParallelism() const = 0;
+    virtual routing_modes_t getRoutingMode() const = 0;
+    virtual bool isUsed() const { return used_; }
+    virtual bool isGPUOperator() const { return false; }
+    virtual bool isWindowed() const { return false; }
+    // type names used for the inter-operator type check (the reference compares
+    // typeid(T).name() strings, pipegraph.hpp:1573-1578)
+    virtual const std::type_info& input_type() const = 0;
+    virtual const std::type_info& output_type() const = 0;
+    // materialise the operator into stages owned by `g`
+    virtual std::vector<StageSpec> build_stages(rt::Graph& g, Mode mode) = 0;
+    // after a nested window operator the next operator must shuffle (A.12)
+    virtual bool forces_shuffle_after() const { return false; }
+    // statistics of every replica (filled at the end of the run)
+    virtual std::vector<Stats_Record> get_StatsRecords() const {
+        std::lock_guard<std::mutex> l(hub_->m);
+        return hub_->recs;
+    }
+
+    void mark_used() { used_ = true; }
+    std::shared_ptr<StatsHub> stats_hub() const { return hub_; }
+
+protected:
+    bool used_ = false;
+    std::shared_ptr<StatsHub> hub_ = std::make_shared<StatsHub>();
+};
+
+}  // namespace wf

@@ -1,0 +1,182 @@
+// Node: the unit of computation of the native runtime.
+//
+// Behavioural contract taken from what the reference needs from FastFlow
+// (SURVEY.md §2.7): a node has svc_init / svc / eosnotify / svc_end, can send to
+// "the next stage" or to a specific destination, and several nodes can be fused
+// into one thread (the reference's ff_comb / combine_with_laststage).  The design
+// is ours: a node owns a vector of output *ports*; a port is either a lock-free
+// SPSC ring to a node running in another thread, or a direct call into a node
+// fused in the same thread.  Fusion is therefore a wiring decision, not a
+// different node type, and emitters / ordering nodes / replicas / collectors are
+// all plain nodes.
+#pragma once
+#include <atomic>
+#include <cassert>
+#include <chrono>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <thread>
+#include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <sched.h>
+
+#include "config.hpp"
+#include "spsc_queue.hpp"
+
+namespace wf {
+namespace rt {
+
+// sentinel pushed on every queue by a terminating producer
+inline void* eos_token() {
+    static char token;
+    return &token;
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    _mm_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// spin -> yield -> sleep back-off helper
+class Backoff {
+public:
+    explicit Backoff(const RuntimeConfig* cfg) : cfg_(cfg) {}
+    void reset() { n_ = 0; }
+    void pause() {
+        const unsigned spin = cfg_->blocking ? 0 : cfg_->spin_iters;
+        if (n_ < spin) {
+            cpu_relax();
+        } else if (n_ < spin + cfg_->yield_iters) {
+            sched_yield();
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(cfg_->sleep_us));
+        }
+        n_++;
+    }
+
+private:
+    const RuntimeConfig* cfg_;
+    unsigned n_ = 0;
+};
+
+// cheap always-on counters (the reference only has them under -DTRACE_WINDFLOW)
+struct NodeCounters {
+    uint64_t inputs = 0;
+    uint64_t outputs = 0;
+    uint64_t busy_ns = 0;  // filled by the thread loop (sampled)
+};
+
+class Graph;
+
+class Node {
+public:
+    Node() = default;
+    virtual ~Node() = default;
+    Node(const Node&) = delete;
+    Node& operator=(const Node&) = delete;
+
+    // ---- user-overridable behaviour -------------------------------------
+    virtual void svc_init() {}
+    // process one message received on input channel `channel`
+    virtual void svc(void* /*msg*/, int /*channel*/) {}
+    // source nodes: produce some output, return false when the stream is over
+    virtual bool generate() { return false; }
+    virtual bool is_source() const { return false; }
+    // one input channel reached end-of-stream
+    virtual void eosnotify(int /*channel*/) {}
+    // every input channel reached end-of-stream: emit whatever is still buffered
+    virtual void flush() {}
+    virtual void svc_end() {}
+
+    // ---- output ---------------------------------------------------------
+    size_t add_out_port() {
+        out_.emplace_back();
+        return out_.size() - 1;
+    }
+    size_t num_out() const { return out_.size(); }
+    size_t num_in() const { return n_in_; }
+
+    // send to port `p` (blocks with back-off while the ring is full)
+    inline void emit_to(void* m, size_t p) {
+        assert(p < out_.size());
+        Port& o = out_[p];
+        counters_.outputs++;
+        if (o.fused != nullptr) {
+            o.fused->counters_.inputs++;
+            o.fused->svc(m, o.fused_ch);
+        } else if (o.q != nullptr) {
+            if (!o.q->try_push(m)) push_slow(o.q, m);
+        }
+        // unconnected port: message is dropped by design (caller keeps ownership rules)
+    }
+    // send to "the next stage": the only port, or round-robin over the ports
+    inline void emit(void* m) {
+        if (out_.size() == 1) {
+            emit_to(m, 0);
+        } else if (!out_.empty()) {
+            emit_to(m, rr_);
+            rr_ = (rr_ + 1 == out_.size()) ? 0 : rr_ + 1;
+        }
+    }
+    bool has_output() const { return !out_.empty(); }
+
+    const NodeCounters& counters() const { return counters_; }
+    const std::string& node_name() const { return node_name_; }
+    void set_node_name(const std::string& n) { node_name_ = n; }
+    const RuntimeConfig& runtime_config() const { return *cfg_; }
+
+    // called by the runtime (or by a fused predecessor) when input `ch` is over
+    void input_ended(int ch) {
+        eosnotify(ch);
+        eos_seen_++;
+        if (eos_seen_ >= n_in_) terminate();
+    }
+    // flush + propagate end-of-stream on every port
+    void terminate() {
+        if (terminated_) return;
+        terminated_ = true;
+        flush();
+        for (Port& o : out_) {
+            if (o.fused != nullptr)
+                o.fused->input_ended(o.fused_ch);
+            else if (o.q != nullptr)
+                push_slow(o.q, eos_token());
+        }
+    }
+
+private:
+    friend class Graph;
+    struct Port {
+        Node* fused = nullptr;
+        int fused_ch = 0;
+        SPSCQueue* q = nullptr;
+    };
+
+    void push_slow(SPSCQueue* q, void* m) {
+        Backoff b(cfg_);
+        while (!q->try_push(m)) b.pause();
+    }
+
+    std::vector<Port> out_;
+    std::vector<SPSCQueue*> in_;  // queue inputs (head nodes only); channel id == index
+    size_t n_in_ = 0;             // number of input channels (queue or fused)
+    size_t eos_seen_ = 0;
+    size_t rr_ = 0;
+    bool terminated_ = false;
+    NodeCounters counters_;
+    std::string node_name_;
+    static const RuntimeConfig* default_cfg() {
+        static RuntimeConfig c = RuntimeConfig::from_env();
+        return &c;
+    }
+    const RuntimeConfig* cfg_ = default_cfg();
+};
+
+}  // namespace rt
+}  // namespace wf

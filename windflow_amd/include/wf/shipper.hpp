@@ -1,0 +1,37 @@
+// Shipper: output handle given to loop-mode Source functions and to FlatMap
+// functions (API parity: /root/reference/wf/shipper.hpp:51-104).
+#pragma once
+#include <cstddef>
+#include <utility>
+
+#include "rt/node.hpp"
+
+namespace wf {
+
+template <typename result_t>
+class Shipper {
+public:
+    explicit Shipper(rt::Node* node) : node_(node) {}
+    // copy semantics
+    void push(const result_t& r) {
+        node_->emit(new result_t(r));
+        delivered_++;
+    }
+    // move semantics
+    void push(result_t&& r) {
+        node_->emit(new result_t(std::move(r)));
+        delivered_++;
+    }
+    // ownership transfer of a heap object created with new
+    void push(result_t* r) {
+        node_->emit(r);
+        delivered_++;
+    }
+    unsigned long delivered() const { return delivered_; }
+
+private:
+    rt::Node* node_;
+    unsigned long delivered_ = 0;
+};
+
+}  // namespace wf
