@@ -1,0 +1,74 @@
+"""In-tree build of the native extension and of the C++ test/benchmark programs.
+
+Everything is compiled for gfx950 only (hipcc cross-compiles without a GPU).
+The built artefacts stay inside the repository tree so they travel to the GPU
+box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+INCLUDE = os.path.join(ROOT, "include")
+CSRC = os.path.join(ROOT, "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def ext_path():
+    return os.path.join(ROOT, "_C" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _newest_mtime(paths):
+    newest = 0.0
+    for p in paths:
+        if os.path.isdir(p):
+            for d, _, files in os.walk(p):
+                for f in files:
+                    newest = max(newest, os.path.getmtime(os.path.join(d, f)))
+        elif os.path.exists(p):
+            newest = max(newest, os.path.getmtime(p))
+    return newest
+
+
+def _pybind_includes():
+    import pybind11
+
+    return ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+
+
+def build_extension(force=False, verbose=True):
+    """Compile windflow_amd/_C*.so (pybind11 + HIP kernels) if missing or stale."""
+    out = ext_path()
+    srcs = [os.path.join(CSRC, "wf_ext.hip")]
+    deps = [INCLUDE, CSRC]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_mtime(deps):
+        return out
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
+    cmd += _pybind_includes() + srcs + ["-o", out, "-lpthread"]
+    rccl_inc = "/opt/rocm/include/rccl"
+    if os.path.isdir(rccl_inc):
+        cmd += ["-I" + rccl_inc, "-L/opt/rocm/lib", "-lrccl"]
+    if verbose:
+        print("[windflow_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_cpp(src, out, hip=False, extra=()):
+    """Compile one C++ (g++) or HIP (hipcc) program against the library headers."""
+    if os.path.exists(out) and os.path.getmtime(out) >= max(_newest_mtime([INCLUDE]), os.path.getmtime(src)):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if hip:
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC, src, "-o", out, "-lpthread"]
+    else:
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I" + INCLUDE, src, "-o", out, "-pthread"]
+    cmd += list(extra)
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    build_extension(force="--force" in sys.argv)

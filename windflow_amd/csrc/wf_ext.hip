@@ -1,0 +1,192 @@
+// Python extension (pybind11, built with hipcc for gfx950): exposes
+//   * kernel-level entry points used by the numerics tests (device pointers come
+//     from torch tensors, results are compared against plain PyTorch references)
+//   * persistent benchmark pipelines built from the C++ library (PipeGraph,
+//     Batch_Source, Map_GPU, Filter_GPU, ...) that bench.py drives step by step.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <wf/windflow.hpp>
+#include <wf/windflow_gpu.hpp>
+
+#include "bench_common.hpp"
+
+namespace py = pybind11;
+using namespace wf;
+using wfbench::tuple_t;
+
+// ---------------------------------------------------------------------------
+// kernel-level entry points (pointers are device addresses, stream 0)
+// ---------------------------------------------------------------------------
+struct ScaleValue {
+    double factor;
+    __host__ __device__ void operator()(tuple_t& t) const { t.value = t.value * factor + t.aux; }
+};
+struct ValueBelow {
+    double threshold;
+    __host__ __device__ bool operator()(const tuple_t& t) const { return t.value < threshold; }
+};
+struct EvenKeyMask {
+    __host__ __device__ void operator()(const tuple_t& t, bool& keep) const { keep = (t.key & 1) == 0; }
+};
+
+static void check_ptr(uintptr_t p, const char* what) {
+    if (p == 0) throw std::invalid_argument(std::string("null device pointer: ") + what);
+}
+
+// in-place map over n tuples: value = value*factor + aux
+static void map_scale_inplace(uintptr_t tuples, size_t n, double factor) {
+    check_ptr(tuples, "tuples");
+    gpu::DeviceBuffer<gpu::BatchHeader> hdr(1);
+    gpu::BatchHeader h{};
+    h.count = (uint32_t)n;
+    WF_HIP_CHECK(hipMemcpy(hdr.data(), &h, sizeof(h), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((gpu::map_inplace_kernel<tuple_t, ScaleValue>), dim3(gpu::grid_for(n)), dim3(gpu::BLOCK_THREADS), 0, 0, hdr.data(),
+                       reinterpret_cast<tuple_t*>(tuples), ScaleValue{factor});
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipDeviceSynchronize());
+}
+
+// stable compaction of the tuples with value < threshold (mode 0) or even key (mode 1);
+// returns the number of survivors
+static size_t filter_compact(uintptr_t in, size_t n, uintptr_t out, int mode, double threshold) {
+    check_ptr(in, "in");
+    check_ptr(out, "out");
+    gpu::DeviceBuffer<gpu::BatchHeader> hdr(2);
+    gpu::BatchHeader h{};
+    h.count = (uint32_t)n;
+    WF_HIP_CHECK(hipMemcpy(hdr.data(), &h, sizeof(h), hipMemcpyHostToDevice));
+    const size_t words = gpu::filter_workspace_words(std::max<size_t>(n, 1));
+    gpu::DeviceBuffer<unsigned long long> ws(words);
+    WF_HIP_CHECK(hipMemset(ws.data(), 0, words * sizeof(unsigned long long)));
+    gpu::PinnedBuffer<uint32_t> mirror(16);
+    mirror[0] = 0xffffffffu;
+    const unsigned grid = (unsigned)std::max<size_t>(1, (n + gpu::FILTER_TILE - 1) / gpu::FILTER_TILE);
+    if (mode == 0) {
+        using P = gpu::PredicateAdapter<tuple_t, ValueBelow>;
+        hipLaunchKernelGGL((gpu::filter_compact_kernel<tuple_t, P>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, 0, hdr.data(),
+                           reinterpret_cast<const tuple_t*>(in), hdr.data() + 1, reinterpret_cast<tuple_t*>(out), mirror.data(), ws.data(),
+                           P{ValueBelow{threshold}});
+    } else {
+        using P = gpu::PredicateAdapter<tuple_t, EvenKeyMask>;
+        hipLaunchKernelGGL((gpu::filter_compact_kernel<tuple_t, P>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, 0, hdr.data(),
+                           reinterpret_cast<const tuple_t*>(in), hdr.data() + 1, reinterpret_cast<tuple_t*>(out), mirror.data(), ws.data(),
+                           P{EvenKeyMask{}});
+    }
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipDeviceSynchronize());
+    gpu::BatchHeader oh{};
+    WF_HIP_CHECK(hipMemcpy(&oh, hdr.data() + 1, sizeof(oh), hipMemcpyDeviceToHost));
+    if (oh.count != mirror[0]) throw std::runtime_error("filter_compact: device header and pinned mirror disagree");
+    return oh.count;
+}
+
+// ---------------------------------------------------------------------------
+// benchmark pipelines
+// ---------------------------------------------------------------------------
+struct SinkTotals {
+    std::mutex m;
+    uint64_t tuples = 0;
+    double value_sum = 0.0;
+    uint64_t batches = 0;
+};
+
+// S gated batch sources -> Map_GPU (in place) -> Filter_GPU (compaction) -> D2H -> batch sink
+// (BASELINE.json config 2; reference workload: gpu_map_stateless.cpp + gpu_filter_stateless.cpp)
+class MapFilterPipeline {
+public:
+    MapFilterPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, size_t inflight)
+        : n_sources_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("map_filter_gpu", Mode::DEFAULT) {
+        auto totals = totals_ = std::make_shared<SinkTotals>();
+        auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
+        wfbench::GatedGenerator gen(gates_.get(), n_keys, 1, n_sources);
+        source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
+                      .withGPUConfiguration(gpu_id).build_unique();
+        MultiPipe& mp = graph_.add_source(*source_);
+        map_ = MapGPU_Builder(ScaleValue{2.0}).withName("map_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                   .withGPUConfiguration(gpu_id).build_unique();
+        mp.add(*map_);
+        filter_ = FilterGPU_Builder(ValueBelow{1024.0}).withName("filter_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                      .withGPUConfiguration(gpu_id).build_unique();
+        mp.chain(*filter_);
+        auto sink_f = [totals, barrier](const tuple_t* data, size_t n, const gpu::BatchHeader& h) {
+            double s = 0.0;
+            for (size_t i = 0; i < n; i++) s += data[i].value;
+            {
+                std::lock_guard<std::mutex> l(totals->m);
+                totals->tuples += n;
+                totals->value_sum += s;
+                totals->batches += (data != nullptr);
+            }
+            if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
+        };
+        sink_ = BatchSink_Builder(sink_f).withName("sink").withParallelism(n_sources).build_unique();
+        mp.chain_sink(*sink_);
+        latency_ = sink_->latency();
+        graph_.start();
+    }
+    ~MapFilterPipeline() { close(); }
+
+    // feed `tuples_per_source` tuples from every source and wait until every result reached the sinks
+    void step(int64_t tuples_per_source) {
+        py::gil_scoped_release rel;
+        step_id_++;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
+        barrier_->wait(step_id_, (int)n_sources_);
+    }
+    void close() {
+        if (closed_) return;
+        closed_ = true;
+        py::gil_scoped_release rel;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].shutdown();
+        graph_.wait_end();
+    }
+    py::dict stats() {
+        py::dict d;
+        std::lock_guard<std::mutex> l(totals_->m);
+        d["sink_tuples"] = totals_->tuples;
+        d["sink_value_sum"] = totals_->value_sum;
+        d["sink_batches"] = totals_->batches;
+        d["latency_p50_us"] = latency_->percentile_us(50);
+        d["latency_p99_us"] = latency_->percentile_us(99);
+        d["latency_mean_us"] = latency_->mean_us();
+        d["threads"] = graph_.getNumThreads();
+        return d;
+    }
+    void reset_latency() { latency_->clear(); }
+    std::string dot() { return graph_.get_DOTGraph(); }
+
+private:
+    size_t n_sources_;
+    std::unique_ptr<wfbench::StepGate[]> gates_;
+    PipeGraph graph_;
+    std::shared_ptr<SinkTotals> totals_;
+    std::shared_ptr<wfbench::StepBarrier> barrier_;
+    std::shared_ptr<LatencyRecorder> latency_;
+    std::unique_ptr<Batch_Source<tuple_t>> source_;
+    std::unique_ptr<Map_GPU<tuple_t, tuple_t>> map_;
+    std::unique_ptr<Filter_GPU<tuple_t>> filter_;
+    std::unique_ptr<Batch_Sink<tuple_t>> sink_;
+    uint64_t step_id_ = 0;
+    bool closed_ = false;
+};
+
+PYBIND11_MODULE(_C, m) {
+    m.doc() = "windflow_amd native extension (gfx950)";
+    m.def("device_count", &gpu::device_count);
+    m.def("tuple_size", []() { return sizeof(tuple_t); });
+    m.def("map_scale_inplace", &map_scale_inplace, py::arg("tuples"), py::arg("n"), py::arg("factor"));
+    m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
+    py::class_<MapFilterPipeline>(m, "MapFilterPipeline")
+        .def(py::init<int, size_t, size_t, size_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"),
+             py::arg("inflight") = 6)
+        .def("step", &MapFilterPipeline::step)
+        .def("close", &MapFilterPipeline::close)
+        .def("stats", &MapFilterPipeline::stats)
+        .def("reset_latency", &MapFilterPipeline::reset_latency)
+        .def("dot", &MapFilterPipeline::dot);
+}

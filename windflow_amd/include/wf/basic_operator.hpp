@@ -50,6 +50,14 @@ struct StageSpec {
     bool internal = false;  // fed by the previous stage of the same operator
 };
 
+// What flows on the edge leaving an operator: individual heap tuples, batches in
+// pinned host memory, or batches resident in device memory.  The MultiPipe
+// negotiates the kind between consecutive operators and inserts adapter nodes
+// (device->host copy, un-batching) where the consumer cannot take batches.  This
+// generalises the reference's manual have_gpu_input / have_gpu_output flags
+// (/root/reference/wf/map_gpu.hpp:148-149, wf/builders_gpu.hpp:1512-1520).
+enum edge_kind_t { EDGE_TUPLE = 0, EDGE_HOST_BATCH = 1, EDGE_DEVICE_BATCH = 2 };
+
 // where replicas deposit their statistics at svc_end (shared with the operator)
 struct StatsHub {
     std::mutex m;
@@ -75,6 +83,13 @@ public:
     virtual const std::type_info& output_type() const = 0;
     // materialise the operator into stages owned by `g`
     virtual std::vector<StageSpec> build_stages(rt::Graph& g, Mode mode) = 0;
+    // edge negotiation (see edge_kind_t)
+    virtual edge_kind_t output_kind() const { return EDGE_TUPLE; }
+    virtual bool accepts_input_kind(edge_kind_t k) const { return k == EDGE_TUPLE; }
+    virtual void set_input_kind(edge_kind_t) {}
+    // node converting this operator's output one step towards tuples
+    // (DEVICE_BATCH -> HOST_BATCH -> TUPLE); nullptr if the operator emits tuples
+    virtual std::function<rt::Node*(edge_kind_t from)> output_adapter_factory() const { return nullptr; }
     // after a nested window operator the next operator must shuffle (A.12)
     virtual bool forces_shuffle_after() const { return false; }
     // statistics of every replica (filled at the end of the run)

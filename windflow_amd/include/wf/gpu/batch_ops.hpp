@@ -1,0 +1,416 @@
+// Batch transport between host operators and GPU operators:
+//   Batch_Source   source that writes tuples straight into pinned slabs
+//   Batch_Sink     sink that consumes whole host batches (+ latency histogram)
+//   DeviceToHost   adapter node: device batch -> pinned host batch (async D2H)
+//   Unbatcher      adapter node: host batch -> individual heap tuples
+//   GPU_Replica    base class of the batched GPU replicas (Map_GPU, Filter_GPU...)
+//
+// The reference ships batches from its benchmark Sources with two pinned buffers
+// and two streams (gpu_map_stateful.cpp:222-226, :330-349) and re-emits results
+// one tuple at a time from the GPU node (wf/map_gpu_node.hpp:476-486).  Here the
+// transport is part of the library: slabs come from bounded stream-ordered pools
+// (hip_utils.hpp), a GPU replica never blocks on the device in steady state, and
+// the device->host direction is a pipelined adapter that the MultiPipe inserts
+// only when the consumer is a CPU operator.
+#pragma once
+#include <algorithm>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../simple_operator.hpp"
+#include "hip_utils.hpp"
+
+namespace wf {
+
+struct GPUConfig {
+    int gpu_id = 0;
+    size_t batch_len = 65536;       // tuples per batch when the operator builds batches itself
+    size_t n_thread_block = DEFAULT_GPU_THREADS_PER_BLOCK;
+    size_t pool_slabs = 6;          // slabs per pool = batches in flight (back-pressure)
+    size_t scratchpad_size = 0;     // per-key (keyed map/filter) or per-thread (windows) bytes
+};
+
+// ---- latency accounting (BASELINE.json asks for p99; the reference only has a
+// mean, src/yahoo_test_cpu/ysb_nodes.hpp:194-218) --------------------------------
+class LatencyRecorder {
+public:
+    void add(uint64_t ns, uint64_t weight = 1) {
+        std::lock_guard<std::mutex> l(m_);
+        samples_.push_back({ns, weight});
+    }
+    // weighted percentile in microseconds (p in [0,100])
+    double percentile_us(double p) const {
+        std::lock_guard<std::mutex> l(m_);
+        if (samples_.empty()) return 0.0;
+        std::vector<std::pair<uint64_t, uint64_t>> s = samples_;
+        std::sort(s.begin(), s.end());
+        uint64_t total = 0;
+        for (auto& x : s) total += x.second;
+        const double target = p / 100.0 * (double)total;
+        uint64_t acc = 0;
+        for (auto& x : s) {
+            acc += x.second;
+            if ((double)acc >= target) return (double)x.first / 1000.0;
+        }
+        return (double)s.back().first / 1000.0;
+    }
+    double mean_us() const {
+        std::lock_guard<std::mutex> l(m_);
+        long double sum = 0, w = 0;
+        for (auto& x : samples_) {
+            sum += (long double)x.first * x.second;
+            w += x.second;
+        }
+        return w > 0 ? (double)(sum / w / 1000.0) : 0.0;
+    }
+    size_t count() const {
+        std::lock_guard<std::mutex> l(m_);
+        return samples_.size();
+    }
+    void clear() {
+        std::lock_guard<std::mutex> l(m_);
+        samples_.clear();
+    }
+
+private:
+    mutable std::mutex m_;
+    std::vector<std::pair<uint64_t, uint64_t>> samples_;
+};
+
+// ---- adapters ---------------------------------------------------------------
+template <typename T>
+class Unbatcher : public rt::Node {
+public:
+    void svc(void* msg, int) override {
+        gpu::Batch* b = static_cast<gpu::Batch*>(msg);
+        const T* d = b->template data<T>();
+        const size_t n = b->host_hdr.count;
+        for (size_t i = 0; i < n; i++) emit(new T(d[i]));
+        b->release_host();
+    }
+};
+
+template <typename T>
+class DeviceToHost : public rt::Node {
+public:
+    explicit DeviceToHost(size_t depth = 4) : depth_(depth) {}
+    void svc(void* msg, int) override {
+        gpu::Batch* d = static_cast<gpu::Batch*>(msg);
+        if (!stream_) {
+            WF_HIP_CHECK(hipSetDevice(d->device));
+            stream_.reset(new gpu::Stream());
+            pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, d->device, sizeof(T), d->capacity, depth_ + 2));
+        }
+        fifo_.push_back({d, nullptr});
+        pump(false);
+        while (fifo_.size() > depth_) pump(true);
+    }
+    void flush() override {
+        while (!fifo_.empty()) pump(true);
+        if (stream_) stream_->sync();
+    }
+    bool wants_idle() const override { return true; }
+    void on_idle() override {
+        if (!fifo_.empty()) pump(false);
+    }
+
+private:
+    struct InFlight {
+        gpu::Batch* dev;
+        gpu::Batch* host;  // nullptr until the copy has been enqueued
+    };
+    // advance the head of the FIFO; `block` waits for the head's current step
+    void pump(bool block) {
+        while (!fifo_.empty()) {
+            InFlight& f = fifo_.front();
+            if (f.host == nullptr) {
+                // step 1: the count must be known on the host before sizing the copy
+                if (!f.dev->count_on_host) {
+                    if (block)
+                        f.dev->ready.host_sync();
+                    else if (!f.dev->ready.done())
+                        return;
+                    f.dev->host_hdr.count = *f.dev->count_mirror;
+                    f.dev->count_on_host = true;
+                }
+                gpu::Batch* h = pool_->acquire_host();
+                h->host_hdr = f.dev->host_hdr;
+                f.dev->ready.wait_on(*stream_);
+                const size_t bytes = (size_t)h->host_hdr.count * sizeof(T);
+                if (bytes > 0) WF_HIP_CHECK(hipMemcpyAsync(h->template data<T>(), f.dev->template data<T>(), bytes, hipMemcpyDeviceToHost, *stream_));
+                h->ready.record(*stream_);
+                f.dev->release(*stream_);
+                f.host = h;
+            }
+            // step 2: copy completion
+            if (block)
+                f.host->ready.host_sync();
+            else if (!f.host->ready.done())
+                return;
+            emit(f.host);
+            fifo_.pop_front();
+            block = false;
+        }
+    }
+    size_t depth_;
+    std::unique_ptr<gpu::Stream> stream_;
+    std::unique_ptr<gpu::BatchPool> pool_;
+    std::deque<InFlight> fifo_;
+};
+
+template <typename T>
+inline std::function<rt::Node*(edge_kind_t)> batch_adapter_factory() {
+    return [](edge_kind_t from) -> rt::Node* {
+        if (from == EDGE_DEVICE_BATCH) return new DeviceToHost<T>();
+        return new Unbatcher<T>();
+    };
+}
+
+// ---- Batch_Source -----------------------------------------------------------
+// Functor forms:  bool(tuple_t&)                          one tuple per call, written in place
+//                 bool(tuple_t* buf, size_t cap, size_t& n) fill up to cap tuples, set n
+// (+ RuntimeContext& as last argument).  false = end of stream.
+template <typename tuple_t, typename F>
+class Batch_Source_Node : public Replica_Base {
+public:
+    Batch_Source_Node(F func, size_t batch_len, size_t slabs, int device, std::string name, size_t par, size_t idx,
+                      meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub)), func_(std::move(func)), batch_len_(batch_len),
+          slabs_(slabs), device_(device) {
+        set_io_bytes(0, sizeof(tuple_t) * batch_len);
+    }
+    bool is_source() const override { return true; }
+    void svc_init() override {
+        Replica_Base::svc_init();
+        WF_HIP_CHECK(hipSetDevice(device_));
+        pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, device_, sizeof(tuple_t), batch_len_, slabs_));
+    }
+    bool generate() override {
+        gpu::Batch* b = pool_->acquire_host();
+        b->host_hdr.created_ns = current_time_nsecs();
+        b->host_hdr.source_id = (uint32_t)context.getReplicaIndex();
+        b->host_hdr.first_seq = seq_;
+        tuple_t* buf = b->template data<tuple_t>();
+        size_t n = 0;
+        bool more = true;
+        if constexpr (meta::base_arity_v<F> == 3) {
+            more = meta::invoke_rich(func_, context, buf, batch_len_, n);
+        } else {
+            while (n < batch_len_ && more) {
+                new (&buf[n]) tuple_t();
+                more = meta::invoke_rich(func_, context, buf[n]);
+                n++;
+            }
+        }
+        b->host_hdr.count = (uint32_t)n;
+        if (n > 0) b->host_hdr.watermark = ts_of(buf[n - 1]);
+        seq_ += n;
+        if constexpr (has_punctuation<F>::value) b->host_hdr.reserved[0] = func_.punctuation();
+        if constexpr (has_opened_ns<F>::value) b->host_hdr.created_ns = func_.opened_ns();
+        if (n > 0 || b->host_hdr.reserved[0] != 0)
+            emit(b);
+        else
+            b->release_host();
+        return more;
+    }
+
+private:
+    // optional hook: uint64_t F::punctuation() - a non-zero value marks the batch as
+    // the last one of a driver-defined step (header.reserved[0]); every batch
+    // operator forwards it, so a sink can tell when a step has fully drained
+    template <typename G, typename = void>
+    struct has_punctuation : std::false_type {};
+    template <typename G>
+    struct has_punctuation<G, std::void_t<decltype(std::declval<G&>().punctuation())>> : std::true_type {};
+    // optional hook: uint64_t F::opened_ns() - host clock when the first tuple of the
+    // batch was produced (default: when generate() was entered)
+    template <typename G, typename = void>
+    struct has_opened_ns : std::false_type {};
+    template <typename G>
+    struct has_opened_ns<G, std::void_t<decltype(std::declval<G&>().opened_ns())>> : std::true_type {};
+    F func_;
+    size_t batch_len_, slabs_;
+    int device_;
+    uint64_t seq_ = 0;
+    std::unique_ptr<gpu::BatchPool> pool_;
+};
+
+template <typename tuple_t>
+class Batch_Source : public Simple_Operator<void, tuple_t> {
+public:
+    template <typename F>
+    Batch_Source(F func, size_t parallelism, std::string name, size_t batch_len, size_t slabs = 6, int device = 0,
+                 meta::closing_func_t closing = nullptr)
+        : Simple_Operator<void, tuple_t>(name, parallelism, NONE, nullptr,
+                                         [=](size_t i, size_t n, std::shared_ptr<StatsHub> hub) -> rt::Node* {
+                                             return new Batch_Source_Node<tuple_t, F>(func, batch_len, slabs, device, name, n, i, closing,
+                                                                                     std::move(hub));
+                                         }) {}
+    edge_kind_t output_kind() const override { return EDGE_HOST_BATCH; }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<tuple_t>(); }
+};
+
+// ---- Batch_Sink --------------------------------------------------------------
+// Functor: void(const tuple_t* data, size_t n) or
+//          void(const tuple_t* data, size_t n, const gpu::BatchHeader&)  [+ RuntimeContext&];
+// called with (nullptr, 0) at end of stream.
+template <typename tuple_t, typename F>
+class Batch_Sink_Node : public Replica_Base {
+public:
+    Batch_Sink_Node(F func, std::shared_ptr<LatencyRecorder> lat, std::string name, size_t par, size_t idx, meta::closing_func_t closing,
+                    std::shared_ptr<StatsHub> hub)
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub)), func_(std::move(func)), lat_(std::move(lat)) {}
+    void svc(void* msg, int) override {
+        gpu::Batch* b = static_cast<gpu::Batch*>(msg);
+        if constexpr (meta::base_arity_v<F> == 3)
+            meta::invoke_rich(func_, context, static_cast<const tuple_t*>(b->template data<tuple_t>()), (size_t)b->host_hdr.count,
+                              static_cast<const gpu::BatchHeader&>(b->host_hdr));
+        else
+            meta::invoke_rich(func_, context, static_cast<const tuple_t*>(b->template data<tuple_t>()), (size_t)b->host_hdr.count);
+        if (lat_ && b->host_hdr.created_ns != 0) lat_->add(current_time_nsecs() - b->host_hdr.created_ns, b->host_hdr.count ? b->host_hdr.count : 1);
+        b->release_host();
+    }
+    void flush() override {
+        if constexpr (meta::base_arity_v<F> == 3) {
+            gpu::BatchHeader h{};
+            meta::invoke_rich(func_, context, static_cast<const tuple_t*>(nullptr), (size_t)0, static_cast<const gpu::BatchHeader&>(h));
+        } else {
+            meta::invoke_rich(func_, context, static_cast<const tuple_t*>(nullptr), (size_t)0);
+        }
+    }
+
+private:
+    F func_;
+    std::shared_ptr<LatencyRecorder> lat_;
+};
+
+template <typename tuple_t>
+class Batch_Sink : public Simple_Operator<tuple_t, void> {
+public:
+    template <typename F>
+    Batch_Sink(F func, size_t parallelism, std::string name, meta::closing_func_t closing = nullptr)
+        : Simple_Operator<tuple_t, void>(name, parallelism, FORWARD, nullptr, nullptr), lat_(std::make_shared<LatencyRecorder>()) {
+        auto lat = lat_;
+        this->factory_ = [func, lat, name, closing](size_t i, size_t n, std::shared_ptr<StatsHub> hub) -> rt::Node* {
+            return new Batch_Sink_Node<tuple_t, F>(func, lat, name, n, i, closing, std::move(hub));
+        };
+    }
+    bool accepts_input_kind(edge_kind_t k) const override { return k == EDGE_HOST_BATCH; }
+    std::shared_ptr<LatencyRecorder> latency() const { return lat_; }
+
+private:
+    std::shared_ptr<LatencyRecorder> lat_;
+};
+
+// ---- base of the batched GPU replicas ----------------------------------------
+template <typename in_t>
+class GPU_Replica : public Replica_Base {
+public:
+    GPU_Replica(GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx, meta::closing_func_t closing,
+                std::shared_ptr<StatsHub> hub, bool is_win = false)
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), is_win, true), cfg_(cfg), in_kind_(in_kind) {}
+
+    void svc_init() override {
+        Replica_Base::svc_init();
+        WF_HIP_CHECK(hipSetDevice(cfg_.gpu_id));
+        stream_.reset(new gpu::Stream());
+        gpu_init();
+    }
+
+    void svc(void* msg, int) override {
+        switch (in_kind_) {
+            case EDGE_TUPLE: {
+                in_t* t = static_cast<in_t*>(msg);
+                if (staging_ == nullptr) open_staging();
+                staging_->template data<in_t>()[staging_->host_hdr.count++] = *t;
+                staging_->host_hdr.watermark = std::max<uint64_t>(staging_->host_hdr.watermark, ts_of(*t));
+                delete t;
+                if (staging_->host_hdr.count == cfg_.batch_len) {
+                    ship(staging_);
+                    staging_ = nullptr;
+                }
+                break;
+            }
+            case EDGE_HOST_BATCH:
+                ship(static_cast<gpu::Batch*>(msg));
+                break;
+            case EDGE_DEVICE_BATCH: {
+                gpu::Batch* d = static_cast<gpu::Batch*>(msg);
+                d->ready.wait_on(*stream_);
+                process_device(d);
+                break;
+            }
+        }
+    }
+
+    // end of stream: the partial batch goes through the same kernels (the
+    // reference falls back to the CPU here, wf/map_gpu_node.hpp:502-604)
+    void flush() override {
+        if (staging_ != nullptr) {
+            if (staging_->host_hdr.count > 0)
+                ship(staging_);
+            else
+                staging_->release_host();
+            staging_ = nullptr;
+        }
+        gpu_flush();
+    }
+
+    void svc_end() override {
+        if (stream_) stream_->sync();
+        Replica_Base::svc_end();
+    }
+
+protected:
+    virtual void gpu_init() {}
+    virtual void gpu_flush() {}
+    // enqueue the operator's kernels for device batch `d` on stream(); takes ownership of d
+    virtual void process_device(gpu::Batch* d) = 0;
+
+    void finalize_stats(Stats_Record& s) override {
+        s.num_kernels = num_kernels_;
+        s.bytes_copied_hd = bytes_hd_;
+        s.bytes_copied_dh = bytes_dh_;
+    }
+    hipStream_t stream() const { return stream_->get(); }
+    // record completion on the batch and pass it downstream
+    void emit_device(gpu::Batch* d) {
+        d->ready.record(stream());
+        emit(d);
+    }
+
+    GPUConfig cfg_;
+    edge_kind_t in_kind_;
+    uint64_t num_kernels_ = 0, bytes_hd_ = 0, bytes_dh_ = 0;
+
+private:
+    void open_staging() {
+        if (!staging_pool_)
+            staging_pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, cfg_.gpu_id, sizeof(in_t), cfg_.batch_len, cfg_.pool_slabs));
+        staging_ = staging_pool_->acquire_host();
+        staging_->host_hdr.created_ns = current_time_nsecs();
+    }
+    // host batch -> device batch (async), then run the operator on it
+    void ship(gpu::Batch* h) {
+        if (!dev_in_pool_)
+            dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), h->capacity, cfg_.pool_slabs));
+        gpu::Batch* d = dev_in_pool_->acquire(stream());
+        *h->header() = h->host_hdr;  // the header travels in the slab
+        const size_t bytes = h->bytes_used();
+        WF_HIP_CHECK(hipMemcpyAsync(d->slab, h->slab, bytes, hipMemcpyHostToDevice, stream()));
+        bytes_hd_ += bytes;
+        d->host_hdr = h->host_hdr;
+        d->count_on_host = true;
+        h->release(stream());
+        process_device(d);
+    }
+
+    std::unique_ptr<gpu::Stream> stream_;
+    std::unique_ptr<gpu::BatchPool> staging_pool_;
+    std::unique_ptr<gpu::BatchPool> dev_in_pool_;
+    gpu::Batch* staging_ = nullptr;
+};
+
+}  // namespace wf

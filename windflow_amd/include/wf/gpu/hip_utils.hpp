@@ -1,0 +1,319 @@
+// HIP substrate: error checking that aborts, RAII device / pinned buffers,
+// streams, events, and the stream-ordered batch pools used for host<->device
+// batch shipping.
+//
+// Capability parity with /root/reference/wf/gpu_utils.hpp:43-312 (GPUBuffer,
+// PinnedCPUBuffer, GPUStream, failwith) and with the double-buffered pinned
+// shipping + device-buffer recycling of the reference benchmarks
+// (src/GPU_Tests/new_tests/benchmarks/gpu_map_stateful.cpp:150-349).  Design is
+// ours: batches are [64-byte header | payload] slabs so one hipMemcpyAsync ships
+// count and tuples together; a slab returns to its pool with an event recorded
+// on the last stream that touched it, and the next user waits on that event
+// (stream-ordered recycling: the host thread never blocks in steady state).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace wf {
+namespace gpu {
+
+// the reference's gpuErrChk prints and keeps going (basic.hpp:104-118); we abort
+#define WF_HIP_CHECK(expr)                                                                                        \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) {                                                                                   \
+            std::fprintf(stderr, "WindFlow HIP error: %s (%d) at %s:%d in %s\n", hipGetErrorString(_e), (int)_e, \
+                         __FILE__, __LINE__, #expr);                                                              \
+            std::abort();                                                                                         \
+        }                                                                                                         \
+    } while (0)
+
+[[noreturn]] inline void failwith(const std::string& msg) {
+    std::fprintf(stderr, "WindFlow GPU error: %s\n", msg.c_str());
+    std::abort();
+}
+
+inline int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- RAII device buffer (grow-only resize, like the reference's GPUBuffer) ----
+template <typename T>
+class DeviceBuffer {
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t n) { resize(n); }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : ptr_(o.ptr_), n_(o.n_) {
+        o.ptr_ = nullptr;
+        o.n_ = 0;
+    }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+        if (this != &o) {
+            release();
+            ptr_ = o.ptr_;
+            n_ = o.n_;
+            o.ptr_ = nullptr;
+            o.n_ = 0;
+        }
+        return *this;
+    }
+    // grow to at least n elements (contents are NOT preserved)
+    void resize(size_t n) {
+        if (n <= n_) return;
+        release();
+        WF_HIP_CHECK(hipMalloc((void**)&ptr_, n * sizeof(T)));
+        n_ = n;
+    }
+    void zero(hipStream_t s = nullptr) {
+        if (ptr_) WF_HIP_CHECK(hipMemsetAsync(ptr_, 0, n_ * sizeof(T), s));
+    }
+    T* data() const { return ptr_; }
+    size_t size() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(T); }
+
+private:
+    void release() {
+        if (ptr_) (void)hipFree(ptr_);
+        ptr_ = nullptr;
+        n_ = 0;
+    }
+    T* ptr_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ---- RAII pinned host buffer ----------------------------------------------
+template <typename T>
+class PinnedBuffer {
+public:
+    PinnedBuffer() = default;
+    explicit PinnedBuffer(size_t n) { resize(n); }
+    ~PinnedBuffer() { release(); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    void resize(size_t n) {
+        if (n <= n_) return;
+        release();
+        WF_HIP_CHECK(hipHostMalloc((void**)&ptr_, n * sizeof(T), hipHostMallocDefault));
+        n_ = n;
+    }
+    T* data() const { return ptr_; }
+    T& operator[](size_t i) { return ptr_[i]; }
+    const T& operator[](size_t i) const { return ptr_[i]; }
+    size_t size() const { return n_; }
+
+private:
+    void release() {
+        if (ptr_) (void)hipHostFree(ptr_);
+        ptr_ = nullptr;
+        n_ = 0;
+    }
+    T* ptr_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ---- stream / event ---------------------------------------------------------
+class Stream {
+public:
+    Stream() { WF_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking)); }
+    ~Stream() {
+        if (s_) (void)hipStreamDestroy(s_);
+    }
+    Stream(const Stream&) = delete;
+    Stream& operator=(const Stream&) = delete;
+    hipStream_t get() const { return s_; }
+    operator hipStream_t() const { return s_; }
+    void sync() const { WF_HIP_CHECK(hipStreamSynchronize(s_)); }
+
+private:
+    hipStream_t s_ = nullptr;
+};
+
+class Event {
+public:
+    Event() { WF_HIP_CHECK(hipEventCreateWithFlags(&e_, hipEventDisableTiming)); }
+    ~Event() {
+        if (e_) (void)hipEventDestroy(e_);
+    }
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
+    hipEvent_t get() const { return e_; }
+    void record(hipStream_t s) {
+        WF_HIP_CHECK(hipEventRecord(e_, s));
+        recorded_ = true;
+    }
+    // make stream s wait for the event (no-op if never recorded)
+    void wait_on(hipStream_t s) const {
+        if (recorded_) WF_HIP_CHECK(hipStreamWaitEvent(s, e_, 0));
+    }
+    void host_sync() const {
+        if (recorded_) WF_HIP_CHECK(hipEventSynchronize(e_));
+    }
+    bool done() const {
+        if (!recorded_) return true;
+        hipError_t r = hipEventQuery(e_);
+        if (r == hipSuccess) return true;
+        if (r != hipErrorNotReady) WF_HIP_CHECK(r);
+        return false;
+    }
+
+private:
+    hipEvent_t e_ = nullptr;
+    bool recorded_ = false;
+};
+
+// ---- batches ----------------------------------------------------------------
+// 64-byte header in front of the payload; lives in the same slab as the tuples
+// so it travels with them in one copy.
+struct alignas(64) BatchHeader {
+    uint32_t count;       // number of valid tuples in the payload
+    uint32_t source_id;   // producer replica
+    uint64_t watermark;   // greatest timestamp contained (low-watermark propagation)
+    uint64_t first_seq;   // sequence number of the first tuple (per producer)
+    uint64_t created_ns;  // host clock when the batch was opened (latency accounting)
+    uint64_t reserved[4];
+};
+static_assert(sizeof(BatchHeader) == 64, "BatchHeader must be 64 bytes");
+
+enum class MemKind { PINNED_HOST, DEVICE };
+
+class BatchPool;
+
+// A slab [header | payload] in pinned host memory or in device memory.
+struct Batch {
+    MemKind kind;
+    int device = 0;
+    size_t elem_size = 0;
+    size_t capacity = 0;       // tuples
+    char* slab = nullptr;      // header at slab, payload at slab + 64
+    BatchHeader host_hdr{};    // host-side view of the header (authoritative when count_on_host)
+    bool count_on_host = true; // false: only the device header / count_mirror know the count
+    volatile uint32_t* count_mirror = nullptr;  // pinned word a kernel writes the final count to
+    Event ready;               // producer's completion / last-use event
+    BatchPool* pool = nullptr;
+
+    BatchHeader* header() const { return reinterpret_cast<BatchHeader*>(slab); }
+    template <typename T>
+    T* data() const {
+        return reinterpret_cast<T*>(slab + sizeof(BatchHeader));
+    }
+    size_t bytes_used() const { return sizeof(BatchHeader) + (size_t)host_hdr.count * elem_size; }
+    uint32_t* device_count_ptr() const { return &header()->count; }
+    inline void release(hipStream_t last_use_stream);
+    inline void release_host();
+};
+
+// Bounded pool of equally sized slabs.  acquire() blocks when `max_slabs` are in
+// flight: this is the back-pressure between host producers and the device.
+class BatchPool {
+public:
+    BatchPool(MemKind kind, int device, size_t elem_size, size_t capacity, size_t max_slabs)
+        : kind_(kind), device_(device), elem_size_(elem_size), capacity_(capacity), max_slabs_(max_slabs) {}
+    ~BatchPool() {
+        for (Batch* b : all_) {
+            if (b->slab) {
+                if (kind_ == MemKind::DEVICE)
+                    (void)hipFree(b->slab);
+                else
+                    (void)hipHostFree(b->slab);
+            }
+            if (b->count_mirror) (void)hipHostFree((void*)b->count_mirror);
+            delete b;
+        }
+    }
+    BatchPool(const BatchPool&) = delete;
+    BatchPool& operator=(const BatchPool&) = delete;
+
+    // acquire for use on `stream` (device work) - stream-ordered, host does not block
+    // unless the pool is exhausted
+    Batch* acquire(hipStream_t stream) {
+        Batch* b = pop();
+        b->ready.wait_on(stream);
+        reset(b);
+        return b;
+    }
+    // acquire for CPU writes: waits until the last device use completed
+    Batch* acquire_host() {
+        Batch* b = pop();
+        b->ready.host_sync();
+        reset(b);
+        return b;
+    }
+    void put(Batch* b) {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            free_.push_back(b);
+        }
+        cv_.notify_one();
+    }
+    size_t capacity() const { return capacity_; }
+    size_t elem_size() const { return elem_size_; }
+    size_t allocated() const { return all_.size(); }
+
+private:
+    Batch* pop() {
+        std::unique_lock<std::mutex> l(m_);
+        if (free_.empty() && all_.size() < max_slabs_) {
+            l.unlock();
+            Batch* nb = allocate();
+            l.lock();
+            all_.push_back(nb);
+            return nb;
+        }
+        cv_.wait(l, [this] { return !free_.empty(); });
+        Batch* b = free_.back();
+        free_.pop_back();
+        return b;
+    }
+    static void reset(Batch* b) {
+        b->host_hdr = BatchHeader{};
+        b->count_on_host = true;
+    }
+    Batch* allocate() {
+        Batch* b = new Batch();
+        b->kind = kind_;
+        b->device = device_;
+        b->elem_size = elem_size_;
+        b->capacity = capacity_;
+        b->pool = this;
+        const size_t bytes = sizeof(BatchHeader) + capacity_ * elem_size_;
+        if (kind_ == MemKind::DEVICE) {
+            WF_HIP_CHECK(hipMalloc((void**)&b->slab, bytes));
+            WF_HIP_CHECK(hipHostMalloc((void**)&b->count_mirror, 64, hipHostMallocDefault));
+            *b->count_mirror = 0;
+        } else {
+            WF_HIP_CHECK(hipHostMalloc((void**)&b->slab, bytes, hipHostMallocDefault));
+        }
+        return b;
+    }
+
+    MemKind kind_;
+    int device_;
+    size_t elem_size_, capacity_, max_slabs_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<Batch*> free_;
+    std::vector<Batch*> all_;
+};
+
+inline void Batch::release(hipStream_t last_use_stream) {
+    ready.record(last_use_stream);
+    pool->put(this);
+}
+inline void Batch::release_host() { pool->put(this); }
+
+}  // namespace gpu
+}  // namespace wf

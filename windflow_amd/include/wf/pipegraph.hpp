@@ -98,6 +98,9 @@ private:
     explicit MultiPipe(PipeGraph* g) : graph_(g) {}
 
     void attach(Basic_Operator& op, bool try_chain);
+    // insert adapter nodes until the edge kind satisfies `ok`
+    template <typename Pred>
+    void adapt_tails(Pred ok);
     void check_editable(const char* what) const {
         if (!has_source_) fatal_error(std::string("MultiPipe does not have a Source, ") + what);
         if (has_sink_) fatal_error(std::string("MultiPipe is terminated by a Sink, ") + what);
@@ -115,6 +118,8 @@ private:
     bool fresh_from_split_ = false;  // no operator added yet after a split
     bool force_shuffle_ = false;     // after merges and nested window operators
     std::vector<MultiPipe*> children_;
+    edge_kind_t tail_kind_ = EDGE_TUPLE;                     // what the endpoints emit
+    std::function<rt::Node*(edge_kind_t)> tail_adapter_;     // from the producing operator
     std::vector<size_t> dot_tail_;  // DOT ids of the operators feeding the endpoints
     std::string split_label_;
 };
@@ -130,8 +135,9 @@ public:
     PipeGraph(const PipeGraph&) = delete;
     PipeGraph& operator=(const PipeGraph&) = delete;
 
-    template <typename tuple_t>
-    MultiPipe& add_source(Source<tuple_t>& source) {
+    // any source-like operator (Source<T>, Batch_Source<T>, ...): no input, one stage
+    MultiPipe& add_source(Basic_Operator& source) {
+        if (source.input_type() != typeid(void)) fatal_error("add_source() needs a Source operator");
         if (source.isUsed()) fatal_error("Source operator has already been used in a MultiPipe");
         MultiPipe* mp = new_mp();
         auto stages = source.build_stages(graph_, mode_);
@@ -139,6 +145,8 @@ public:
         for (rt::Node* n : stages[0].replicas) mp->tails_.push_back({n, n->add_out_port()});
         mp->has_source_ = true;
         mp->out_type_ = &source.output_type();
+        mp->tail_kind_ = source.output_kind();
+        mp->tail_adapter_ = source.output_adapter_factory();
         mp->dot_tail_ = {dot_add_node(source.getName(), source.getParallelism(), "Source", false)};
         root_->children.push_back(new_app_node(mp, root_.get()));
         operators_.push_back(&source);
@@ -369,6 +377,9 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         fatal_error("output type of the last operator in the MultiPipe does not match the input type of operator " + op.getName());
     rt::Graph& g = graph_->graph_;
     const Mode mode = graph_->mode_;
+    // edge negotiation: hand batches over when the operator can take them
+    adapt_tails([&op](edge_kind_t k) { return op.accepts_input_kind(k); });
+    op.set_input_kind(tail_kind_);
     std::vector<StageSpec> stages = op.build_stages(g, mode);
     op.mark_used();
     const bool is_sink = (op.output_type() == typeid(void));
@@ -420,6 +431,8 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         out_type_ = &op.output_type();
     }
     if (op.forces_shuffle_after()) force_shuffle_ = true;
+    tail_kind_ = op.output_kind();
+    tail_adapter_ = op.output_adapter_factory();
     // logical graph
     const size_t id = graph_->dot_add_node(op.getName(), op.getParallelism(), is_sink ? "Sink" : (op.isWindowed() ? "Window" : "Operator"),
                                            op.isGPUOperator());
@@ -427,6 +440,20 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
     split_label_.clear();
     dot_tail_ = {id};
     graph_->operators_.push_back(&op);
+}
+
+template <typename Pred>
+inline void MultiPipe::adapt_tails(Pred ok) {
+    while (!ok(tail_kind_)) {
+        if (tail_kind_ == EDGE_TUPLE || !tail_adapter_) fatal_error("operator cannot consume the output of the previous operator");
+        rt::Graph& g = graph_->graph_;
+        for (Endpoint& e : tails_) {
+            rt::Node* a = g.adopt(tail_adapter_(tail_kind_));
+            g.connect_fused(e.node, e.port, a);
+            e = {a, a->add_out_port()};
+        }
+        tail_kind_ = (tail_kind_ == EDGE_DEVICE_BATCH) ? EDGE_HOST_BATCH : EDGE_TUPLE;
+    }
 }
 
 template <typename... MPS>
@@ -444,6 +471,8 @@ inline MultiPipe& MultiPipe::merge(MPS&... others) {
         if (mp->is_split_) fatal_error("MultiPipe has been split, merge its branches instead");
         if (mp->out_type_ == nullptr || *mp->out_type_ != *out_type_) fatal_error("MultiPipes to be merged must have the same output type");
     }
+    // batches are converted back to tuples before a merge
+    for (MultiPipe* mp : ops) mp->adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
     MultiPipe* merged = graph_->new_mp();
     merged->has_source_ = true;
     merged->out_type_ = out_type_;
@@ -465,6 +494,7 @@ inline MultiPipe& MultiPipe::split(F func, size_t cardinality) {
     if (cardinality < 2) fatal_error("split() needs at least two branches");
     using tuple_t = typename meta::split_sig<F>::tuple_t;
     if (*out_type_ != typeid(tuple_t)) fatal_error("input type of the splitting function does not match the output type of the MultiPipe");
+    adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
     rt::Graph& g = graph_->graph_;
     std::vector<rt::Node*> splitters;
     for (Endpoint& e : tails_) {

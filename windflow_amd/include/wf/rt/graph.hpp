@@ -132,6 +132,9 @@ private:
             std::vector<int> active(head->in_.size());
             for (size_t i = 0; i < active.size(); i++) active[i] = (int)i;
             Backoff backoff(&cfg_);
+            std::vector<Node*> idlers;
+            for (Node* n : group)
+                if (n->wants_idle()) idlers.push_back(n);
             while (!active.empty()) {
                 bool progress = false;
                 for (size_t a = 0; a < active.size();) {
@@ -156,10 +159,12 @@ private:
                         a++;
                     }
                 }
-                if (progress)
+                if (progress) {
                     backoff.reset();
-                else
+                } else {
+                    for (Node* n : idlers) n->on_idle();
                     backoff.pause();
+                }
             }
             if (head->in_.empty()) head->terminate();
         }

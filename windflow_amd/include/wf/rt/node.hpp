@@ -93,6 +93,10 @@ public:
     // every input channel reached end-of-stream: emit whatever is still buffered
     virtual void flush() {}
     virtual void svc_end() {}
+    // nodes with asynchronous work in flight (device copies...) can ask to be polled
+    // whenever their thread has no input to process
+    virtual bool wants_idle() const { return false; }
+    virtual void on_idle() {}
 
     // ---- output ---------------------------------------------------------
     size_t add_out_port() {
