@@ -26,10 +26,10 @@ def test_map_inplace_matches_torch(ext, n):
     ext.map_scale_inplace(d.data_ptr(), n, 2.5)
     torch.cuda.synchronize()
     out = d.cpu()
-    ref_val = t[:, 3].view(torch.float64).to(torch.float32).double() * 0  # placeholder to keep fp32 path explicit
     ref_val = t[:, 3].view(torch.float64) * 2.5 + t[:, 4].view(torch.float64)
     assert torch.equal(out[:, :3], t[:, :3])
-    assert torch.allclose(out[:, 3].view(torch.float64), ref_val, rtol=0, atol=0)
+    # the device contracts a*b+c into one fma: allow 1 ulp
+    assert torch.allclose(out[:, 3].view(torch.float64), ref_val, rtol=1e-15, atol=0)
     assert torch.equal(out[:, 4], t[:, 4])
 
 
