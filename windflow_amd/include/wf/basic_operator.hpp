@@ -40,7 +40,10 @@ struct EmitterAssembly {
 struct StageSpec {
     std::string name;
     routing_modes_t routing = FORWARD;
-    std::vector<rt::Node*> replicas;  // already adopted by the graph
+    std::vector<rt::Node*> replicas;  // entry node of each replica, already adopted by the graph
+    // node whose output feeds the next stage, when a replica is a fused chain of
+    // several nodes (empty: same as `replicas`)
+    std::vector<rt::Node*> outputs;
     // build (and adopt into the graph) the emitter used by upstream producer
     // `src_idx` (index of the replica of the previous stage when `internal`, else
     // the index of the upstream endpoint)

@@ -421,7 +421,7 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         fresh_from_split_ = false;
         prev.clear();
         if (!(is_sink && last_stage))
-            for (rt::Node* r : s.replicas) prev.push_back({r, r->add_out_port()});
+            for (rt::Node* r : (s.outputs.empty() ? s.replicas : s.outputs)) prev.push_back({r, r->add_out_port()});
     }
     tails_ = prev;
     if (is_sink) {

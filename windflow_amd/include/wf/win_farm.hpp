@@ -1,0 +1,128 @@
+// Win_Farm: window parallelism.  Consecutive windows of the same key are computed
+// by different replicas; replica i of N owns windows i, i+N, ... and therefore
+// works with a private slide of slide*N; tuples are multicast to every replica
+// owning a window that contains them.  Semantics: /root/reference/wf/
+// win_farm.hpp:124-185 (ctor I), :266-484 (nesting with Pane_Farm /
+// Win_MapReduce), wf/wf_nodes.hpp, SURVEY.md A.4.  With count-based windows the
+// replicas are fed by a broadcast of the renumbered stream (pipegraph.hpp:1953-1958).
+#pragma once
+#include "pane_farm.hpp"
+#include "two_stage.hpp"
+#include "win_mapreduce.hpp"
+
+namespace wf {
+
+template <typename tuple_t, typename result_t>
+class Win_Farm : public Basic_Operator {
+public:
+    // ctor I: a window function replicated `parallelism` times
+    template <typename F, typename = std::enable_if_t<!std::is_base_of_v<Basic_Operator, F>>>
+    Win_Farm(F func, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type, size_t parallelism, std::string name,
+             meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL0)
+        : name_(std::move(name)), win_(win_len), slide_(slide_len), delay_(triggering_delay), type_(type), par_(parallelism),
+          ordered_(ordered), opt_(opt_level) {
+        check_params();
+        auto hub = hub_;
+        const std::string n = name_;
+        const uint64_t win = win_, slide = slide_, delay = delay_;
+        const size_t N = par_;
+        flat_factory_ = [=](rt::Graph& g) {
+            std::vector<rt::Node*> reps;
+            for (size_t i = 0; i < N; i++) {
+                WinParams p;
+                p.win_len = win;
+                p.slide_len = slide * N;
+                p.triggering_delay = delay;
+                p.winType = type;
+                p.config = WinOperatorConfig(0, 1, slide, i, N, slide);
+                p.role = SEQ;
+                reps.push_back(make_win_seq<tuple_t, result_t>(g, func, p, n, N, i, closing, hub));
+            }
+            return reps;
+        };
+    }
+    // ctor II / III: replicate a Pane_Farm or a Win_MapReduce `num_replicas` times
+    Win_Farm(TwoStage_Operator<tuple_t, result_t>& inner, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
+             size_t num_replicas, std::string name, meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL2)
+        : name_(std::move(name)), win_(win_len), slide_(slide_len), delay_(triggering_delay), type_(type), par_(num_replicas),
+          ordered_(ordered), opt_(opt_level), inner_(&inner) {
+        (void)closing;
+        check_params();
+        if (inner.isUsed4Nesting() || inner.isUsed()) fatal_error("inner operator has already been used (nested or in a MultiPipe)");
+        inner.markUsed4Nesting();
+        if (inner.getWinLen() != win_ || inner.getSlideLen() != slide_ || inner.getTriggeringDelay() != delay_ || inner.getWinType() != type_)
+            fatal_error("incompatible windowing parameters between Win_Farm and its inner operator");
+        if (inner.getOptLevel() != LEVEL2 || opt_ != LEVEL2)
+            fatal_error("nesting requires both operators built at LEVEL2 (prepare4Nesting on the inner one)");
+        inner_par_ = inner.getInnerParallelisms();
+    }
+
+    std::string getName() const override { return name_; }
+    size_t getParallelism() const override { return inner_ ? par_ * (inner_par_.first + inner_par_.second) : par_; }
+    routing_modes_t getRoutingMode() const override { return COMPLEX; }
+    bool isWindowed() const override { return true; }
+    const std::type_info& input_type() const override { return typeid(tuple_t); }
+    const std::type_info& output_type() const override { return typeid(result_t); }
+    bool forces_shuffle_after() const override { return inner_ != nullptr; }
+    size_t getNumComplexReplicas() const { return inner_ ? par_ : 0; }
+    std::pair<size_t, size_t> getInnerParallelisms() const { return inner_par_; }
+
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
+        const win_type_t type = type_;
+        const uint64_t win = win_, slide = slide_;
+        const size_t N = par_;
+        if (inner_ != nullptr) {
+            std::vector<TwoStageGroup> groups;
+            for (size_t i = 0; i < N; i++) {
+                NestCtx ctx;
+                ctx.id = i;
+                ctx.n = N;
+                ctx.slide_outer = slide;
+                ctx.slide_mult = N;
+                groups.push_back(inner_->make_group(g, ctx, name_ + "_inner_" + std::to_string(i)));
+            }
+            auto root = [type, win, slide](size_t G) -> rt::Node* {
+                if (type == CB) return new Broadcast_Emitter<tuple_t>(G);
+                return new WF_Emitter<tuple_t>(type, win, slide, G, 0, 1, slide, SEQ);
+            };
+            return assemble_two_stage<tuple_t, result_t>(g, groups, type_, name_, root, ordered_);
+        }
+        StageSpec s;
+        s.name = name_;
+        s.routing = COMPLEX;
+        s.replicas = flat_factory_(g);
+        s.make_emitter = [type, win, slide, N](rt::Graph& gr, size_t) {
+            if (type == CB) return single_emitter(gr, new Broadcast_Emitter<tuple_t>(N), N);
+            return single_emitter(gr, new WF_Emitter<tuple_t>(type, win, slide, N, 0, 1, slide, SEQ), N);
+        };
+        s.make_ordering = window_ordering<tuple_t>(type_, name_);
+        std::vector<StageSpec> out{s};
+        if (ordered_ && N > 1) {
+            StageSpec c;
+            c.name = name_ + "_collector";
+            c.routing = FORWARD;
+            c.internal = true;
+            c.replicas.push_back(g.adopt(new Ordered_Collector<result_t>()));
+            c.make_emitter = [](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<result_t>(1), 1); };
+            out.push_back(c);
+        }
+        return out;
+    }
+
+private:
+    void check_params() const {
+        if (win_ == 0 || slide_ == 0) fatal_error("window length or slide in Win_Farm cannot be zero");
+        if (par_ == 0) fatal_error("Win_Farm has parallelism zero");
+    }
+    std::string name_;
+    uint64_t win_, slide_, delay_;
+    win_type_t type_;
+    size_t par_;
+    bool ordered_;
+    opt_level_t opt_;
+    TwoStage_Operator<tuple_t, result_t>* inner_ = nullptr;
+    std::pair<size_t, size_t> inner_par_{0, 0};
+    std::function<std::vector<rt::Node*>(rt::Graph&)> flat_factory_;
+};
+
+}  // namespace wf
