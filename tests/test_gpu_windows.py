@@ -1,0 +1,167 @@
+"""Device primitives and the keyed FlatFAT engine against PyTorch/NumPy oracles (GPU only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 63, 2047, 2048, 2049, 100_000, 1_000_003])
+def test_exclusive_scan_matches_torch(ext, n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 1000, (n,), generator=g, dtype=torch.int32)
+    d = x.cuda()
+    out = torch.empty_like(d)
+    total = ext.exclusive_scan(d.data_ptr(), out.data_ptr(), n)
+    torch.cuda.synchronize()
+    ref = torch.cumsum(x.to(torch.int64), 0) - x
+    assert total == int(x.sum())
+    assert torch.equal(out.cpu().to(torch.int64), ref)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 8), (1000, 8), (2049, 11), (100_000, 17), (1_000_000, 21), (300_000, 32)])
+def test_radix_sort_pairs_is_stable_and_sorted(ext, n, bits):
+    g = torch.Generator().manual_seed(bits * 7 + n)
+    hi = (1 << bits) if bits < 31 else (1 << 31) - 1
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64)
+    if bits >= 32:
+        keys = keys * 2 + torch.randint(0, 2, (n,), generator=g, dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int64)
+    dk = keys.to(torch.int64).cuda().to(torch.uint32) if hasattr(torch, "uint32") else None
+    # uint32 tensors: go through int32 bit patterns
+    dk = torch.from_numpy(keys.numpy().astype(np.uint32).view(np.int32)).cuda()
+    dv = torch.from_numpy(vals.numpy().astype(np.uint32).view(np.int32)).cuda()
+    ext.radix_sort_pairs(dk.data_ptr(), dv.data_ptr(), n, bits)
+    torch.cuda.synchronize()
+    sk = dk.cpu().numpy().view(np.uint32).astype(np.int64)
+    sv = dv.cpu().numpy().view(np.uint32).astype(np.int64)
+    order = np.argsort(keys.numpy(), kind="stable")
+    assert np.array_equal(sk, keys.numpy()[order])
+    assert np.array_equal(sv, order)  # stability: equal keys keep arrival order
+
+
+def make_stream(n, n_keys, seed, ts_step=1, skew=False):
+    rng = np.random.default_rng(seed)
+    if skew:
+        keys = np.minimum(rng.zipf(1.3, n) - 1, n_keys - 1).astype(np.int64)
+    else:
+        keys = rng.integers(0, n_keys, n).astype(np.int64)
+    t = np.zeros((n, 5), dtype=np.int64)
+    t[:, 0] = keys * 7919 + 3  # sparse key values
+    t[:, 1] = np.arange(n)
+    t[:, 2] = np.arange(n) * ts_step
+    vals = rng.integers(-50, 50, n).astype(np.float64)
+    t[:, 3] = vals.view(np.int64)
+    t[:, 4] = np.float64(1.0).view(np.int64)
+    return t, vals
+
+
+def oracle_cb(t, vals, win, slide):
+    """(key, lwid) -> (sum, last ts); every opened window, partial ones at end of stream."""
+    out = {}
+    for key in np.unique(t[:, 0]):
+        m = t[:, 0] == key
+        v, ts = vals[m], t[m, 2]
+        n = len(v)
+        lw = 0
+        while lw * slide < n:
+            a, b = lw * slide, min(n, lw * slide + win)
+            out[(int(key), lw)] = (float(v[a:b].sum()), int(ts[b - 1]))
+            lw += 1
+    return out
+
+
+def oracle_tb(t, vals, win, slide):
+    q = math.gcd(win, slide)
+    sp = slide // q
+    out = {}
+    for key in np.unique(t[:, 0]):
+        m = t[:, 0] == key
+        v, ts = vals[m], t[m, 2]
+        n_panes = int(ts.max()) // q + 1
+        lw = 0
+        while lw * sp < n_panes:
+            a, b = lw * slide, lw * slide + win
+            sel = (ts >= a) & (ts < b)
+            out[(int(key), lw)] = float(v[sel].sum())
+            lw += 1
+    return out
+
+
+def unpack(res):
+    vals = res[:, 3].copy().view(np.float64)
+    return {(int(k), int(i)): (float(v), int(ts)) for k, i, ts, v in zip(res[:, 0], res[:, 1], res[:, 2], vals)}
+
+
+@pytest.mark.parametrize("n,n_keys,win,slide,batch", [
+    (5000, 7, 10, 3, 512),
+    (20000, 1, 64, 16, 4096),
+    (50000, 1000, 12, 4, 8192),
+    (30000, 5000, 5, 1, 4096),
+    (40000, 50, 100, 7, 65536),
+])
+def test_key_ffat_count_based_matches_oracle(ext, n, n_keys, win, slide, batch):
+    t, vals = make_stream(n, n_keys, seed=n + win)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, False, max(16, n_keys), batch)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0
+    got = unpack(res)
+    exp = oracle_cb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, (s, ts) in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9)
+        assert got[k][1] == ts
+
+
+@pytest.mark.parametrize("n,n_keys,win,slide,batch,ts_step", [
+    (5000, 5, 100, 25, 512, 1),
+    (30000, 300, 4000, 1000, 4096, 1),
+    (20000, 40, 900, 600, 8192, 3),
+])
+def test_key_ffat_time_based_matches_oracle(ext, n, n_keys, win, slide, batch, ts_step):
+    t, vals = make_stream(n, n_keys, seed=n + slide, ts_step=ts_step)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, True, max(16, n_keys), batch, 4 * batch)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    got = unpack(res)
+    exp = oracle_tb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, s in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9)
+
+
+def test_key_ffat_skewed_keys(ext):
+    t, vals = make_stream(60000, 2000, seed=5, skew=True)
+    res, ctr = ext.key_ffat_run(t, 20, 5, 0, False, 4096, 16384)
+    got = unpack(res)
+    exp = oracle_cb(t, vals, 20, 5)
+    assert len(got) == len(exp)
+    for k, (s, _) in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9)
+
+
+def test_win_agg_pipeline_end_to_end(ext):
+    # 2 sources x 50 keys each, count-based window 8 slide 2 over values seq & 1023
+    pipe = ext.WinAggPipeline(0, 2, 4096, 50, 8, 2, False, 0, 4)
+    per_source = 40_000
+    pipe.step(per_source)
+    pipe.step(per_source)
+    st = pipe.stats()
+    pipe.close()
+    st2 = pipe.stats()
+    n = 2 * per_source  # tuples per source, round-robin over 50 keys -> 1600 per key
+    per_key = n // 50
+    fired = (per_key - 8) // 2 + 1  # complete windows per key
+    assert st["sink_tuples"] == 2 * 50 * fired
+    assert st2["sink_tuples"] == 2 * 50 * math.ceil(per_key / 2)  # + partial windows flushed at end of stream
+    # exact sum: window lw of key k (source-local index) covers its elements [2lw, 2lw+8)
+    seq = np.arange(n)
+    vals = (seq & 1023).astype(np.float64)
+    total = 0.0
+    for k in range(50):
+        v = vals[k::50]
+        c = np.concatenate([[0.0], np.cumsum(v)])
+        for lw in range(math.ceil(per_key / 2)):
+            total += c[min(per_key, 2 * lw + 8)] - c[2 * lw]
+    assert st2["sink_value_sum"] == pytest.approx(2 * total, rel=1e-12)
+    assert st2["overflow"] == 0 and st2["table_full"] == 0

@@ -31,6 +31,29 @@ struct tuple_t {
 };
 static_assert(sizeof(tuple_t) == 40, "benchmark tuple must be 40 bytes");
 
+// 32-byte window result
+struct result_t {
+    uint64_t key;
+    uint64_t id;
+    uint64_t ts;
+    double value;
+    __host__ __device__ std::tuple<uint64_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    __host__ __device__ void setControlFields(uint64_t k, uint64_t i, uint64_t t) {
+        key = k;
+        id = i;
+        ts = t;
+    }
+};
+static_assert(sizeof(result_t) == 32, "benchmark result must be 32 bytes");
+
+// lift / combine of the flagship sliding-window sum
+struct LiftValue {
+    __host__ __device__ void operator()(const tuple_t& t, result_t& r) const { r.value = t.value; }
+};
+struct CombSum {
+    __host__ __device__ void operator()(const result_t& a, const result_t& b, result_t& out) const { out.value = a.value + b.value; }
+};
+
 // A driver releases `quota` tuples per step; the source closes the step with a
 // punctuated batch and sleeps until the next step (or stop).
 struct StepGate {

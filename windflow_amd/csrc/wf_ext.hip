@@ -3,6 +3,7 @@
 //     from torch tensors, results are compared against plain PyTorch references)
 //   * persistent benchmark pipelines built from the C++ library (PipeGraph,
 //     Batch_Source, Map_GPU, Filter_GPU, ...) that bench.py drives step by step.
+#include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -17,6 +18,7 @@
 
 namespace py = pybind11;
 using namespace wf;
+using wfbench::result_t;
 using wfbench::tuple_t;
 
 // ---------------------------------------------------------------------------
@@ -175,12 +177,201 @@ private:
     bool closed_ = false;
 };
 
+// ---------------------------------------------------------------------------
+// keyed FlatFAT engine driven directly (numerics tests): tuples is an [n,5] int64
+// array of 40-byte tuples, processed in batches of batch_len; returns an [m,4]
+// int64 array of 32-byte results (key, gwid, ts, value-bits) + the device counters
+// ---------------------------------------------------------------------------
+static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::array::forcecast> tuples, uint64_t win, uint64_t slide,
+                              uint64_t delay, bool time_based, size_t max_keys, size_t batch_len, size_t out_capacity) {
+    auto buf = tuples.request();
+    if (buf.ndim != 2 || buf.shape[1] != 5) throw std::invalid_argument("tuples must be [n,5] int64");
+    const size_t n = (size_t)buf.shape[0];
+    const tuple_t* host = static_cast<const tuple_t*>(buf.ptr);
+    WF_HIP_CHECK(hipSetDevice(0));
+    gpu::Stream stream;
+    if (out_capacity == 0) out_capacity = batch_len;
+    gpu::KeyedFFATEngine<tuple_t, result_t, wfbench::LiftValue, wfbench::CombSum> engine(wfbench::LiftValue{}, wfbench::CombSum{}, win, slide, delay,
+                                                                                          time_based ? TB : CB, max_keys, batch_len, out_capacity,
+                                                                                          0, 3);
+    gpu::BatchPool in_pool(gpu::MemKind::DEVICE, 0, sizeof(tuple_t), batch_len, 2);
+    std::vector<result_t> results;
+    uint64_t kernels = 0;
+    auto drain = [&](gpu::Batch* out) {
+        out->ready.record(stream);
+        stream.sync();
+        const uint32_t cnt = *out->count_mirror;
+        const size_t old = results.size();
+        results.resize(old + cnt);
+        if (cnt) WF_HIP_CHECK(hipMemcpy(results.data() + old, out->data<result_t>(), cnt * sizeof(result_t), hipMemcpyDeviceToHost));
+        out->release(stream);
+    };
+    for (size_t off = 0; off < n; off += batch_len) {
+        const size_t cnt = std::min(batch_len, n - off);
+        gpu::Batch* d = in_pool.acquire(stream);
+        d->host_hdr.count = (uint32_t)cnt;
+        WF_HIP_CHECK(hipMemcpyAsync(d->header(), &d->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, stream));
+        WF_HIP_CHECK(hipMemcpyAsync(d->data<tuple_t>(), host + off, cnt * sizeof(tuple_t), hipMemcpyHostToDevice, stream));
+        gpu::Batch* out = engine.process(d, stream, kernels);
+        d->release(stream);
+        drain(out);
+    }
+    drain(engine.flush(stream, kernels));
+    gpu::FFATCounters c = engine.read_counters(stream);
+    py::array_t<int64_t> arr({(py::ssize_t)results.size(), (py::ssize_t)4});
+    if (!results.empty()) std::memcpy(arr.mutable_data(), results.data(), results.size() * sizeof(result_t));
+    py::dict counters;
+    counters["dropped"] = c.dropped;
+    counters["overflow"] = c.overflow;
+    counters["skipped_windows"] = c.skipped_windows;
+    counters["table_full"] = c.table_full;
+    counters["kernels"] = kernels;
+    counters["device_bytes"] = engine.device_bytes();
+    return py::make_tuple(arr, counters);
+}
+
+// stable radix sort of (key, value) pairs on the device (numerics test of the primitive)
+static void radix_sort_pairs(uintptr_t keys, uintptr_t vals, size_t n, int bits) {
+    check_ptr(keys, "keys");
+    check_ptr(vals, "vals");
+    gpu::DeviceBuffer<uint32_t> n_dev(1);
+    const uint32_t n32 = (uint32_t)n;
+    WF_HIP_CHECK(hipMemcpy(n_dev.data(), &n32, 4, hipMemcpyHostToDevice));
+    gpu::RadixSorter sorter;
+    sorter.sort(reinterpret_cast<uint32_t*>(keys), reinterpret_cast<uint32_t*>(vals), n_dev.data(), n, bits, 0);
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipDeviceSynchronize());
+}
+
+static uint32_t exclusive_scan(uintptr_t in, uintptr_t out, size_t n) {
+    check_ptr(in, "in");
+    check_ptr(out, "out");
+    gpu::DeviceBuffer<unsigned long long> ws(gpu::scan_workspace_words(n));
+    gpu::DeviceBuffer<uint32_t> total(1);
+    gpu::exclusive_scan_u32(reinterpret_cast<const uint32_t*>(in), reinterpret_cast<uint32_t*>(out), n, total.data(), ws.data(), 0);
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipDeviceSynchronize());
+    uint32_t t = 0;
+    WF_HIP_CHECK(hipMemcpy(&t, total.data(), 4, hipMemcpyDeviceToHost));
+    return t;
+}
+
+// S gated batch sources -> Key_FFAT_GPU (device-resident keyed sliding-window sum) -> D2H -> batch sinks
+// (BASELINE.json config 4, the flagship "sliding-window aggregation" pipeline)
+class WinAggPipeline {
+public:
+    WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
+                   size_t inflight)
+        : n_sources_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
+        auto totals = totals_ = std::make_shared<SinkTotals>();
+        auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
+        wfbench::GatedGenerator gen(gates_.get(), n_keys, 1, n_sources);
+        source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
+                      .withGPUConfiguration(gpu_id).build_unique();
+        MultiPipe& mp = graph_.add_source(*source_);
+        KeyFFATGPUConfig wcfg;
+        wcfg.win_len = win;
+        wcfg.slide_len = slide;
+        wcfg.delay = delay;
+        wcfg.type = time_based ? TB : CB;
+        wcfg.max_keys = n_keys;
+        GPUConfig cfg;
+        cfg.gpu_id = gpu_id;
+        cfg.batch_len = batch_len;
+        cfg.pool_slabs = inflight;
+        kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sources, "key_ffat_gpu", cfg));
+        mp.add(*kff_);
+        auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
+            double s = 0.0;
+            for (size_t i = 0; i < n; i++) s += data[i].value;
+            {
+                std::lock_guard<std::mutex> l(totals->m);
+                totals->tuples += n;
+                totals->value_sum += s;
+                totals->batches += (data != nullptr);
+            }
+            if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
+        };
+        sink_ = BatchSink_Builder(sink_f).withName("sink").withParallelism(n_sources).build_unique();
+        mp.chain_sink(*sink_);
+        latency_ = sink_->latency();
+        graph_.start();
+    }
+    ~WinAggPipeline() { close(); }
+    void step(int64_t tuples_per_source) {
+        py::gil_scoped_release rel;
+        step_id_++;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
+        barrier_->wait(step_id_, (int)n_sources_);
+    }
+    void close() {
+        if (closed_) return;
+        closed_ = true;
+        py::gil_scoped_release rel;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].shutdown();
+        graph_.wait_end();
+    }
+    py::dict stats() {
+        py::dict d;
+        {
+            std::lock_guard<std::mutex> l(totals_->m);
+            d["sink_tuples"] = totals_->tuples;
+            d["sink_value_sum"] = totals_->value_sum;
+            d["sink_batches"] = totals_->batches;
+        }
+        d["latency_p50_us"] = latency_->percentile_us(50);
+        d["latency_p99_us"] = latency_->percentile_us(99);
+        d["latency_mean_us"] = latency_->mean_us();
+        d["threads"] = graph_.getNumThreads();
+        uint64_t dropped = 0, overflow = 0, skipped = 0, full = 0;
+        for (auto& c : kff_->getDeviceCounters()) {
+            dropped += c.dropped;
+            overflow += c.overflow;
+            skipped += c.skipped_windows;
+            full += c.table_full;
+        }
+        d["dropped"] = dropped;
+        d["overflow"] = overflow;
+        d["skipped_windows"] = skipped;
+        d["table_full"] = full;
+        return d;
+    }
+    void reset_latency() { latency_->clear(); }
+    std::string dot() { return graph_.get_DOTGraph(); }
+
+private:
+    size_t n_sources_;
+    std::unique_ptr<wfbench::StepGate[]> gates_;
+    PipeGraph graph_;
+    std::shared_ptr<SinkTotals> totals_;
+    std::shared_ptr<wfbench::StepBarrier> barrier_;
+    std::shared_ptr<LatencyRecorder> latency_;
+    std::unique_ptr<Batch_Source<tuple_t>> source_;
+    std::unique_ptr<Key_FFAT_GPU<tuple_t, result_t>> kff_;
+    std::unique_ptr<Batch_Sink<result_t>> sink_;
+    uint64_t step_id_ = 0;
+    bool closed_ = false;
+};
+
 PYBIND11_MODULE(_C, m) {
     m.doc() = "windflow_amd native extension (gfx950)";
     m.def("device_count", &gpu::device_count);
     m.def("tuple_size", []() { return sizeof(tuple_t); });
     m.def("map_scale_inplace", &map_scale_inplace, py::arg("tuples"), py::arg("n"), py::arg("factor"));
     m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
+    m.def("key_ffat_run", &key_ffat_run, py::arg("tuples"), py::arg("win"), py::arg("slide"), py::arg("delay"), py::arg("time_based"),
+          py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0);
+    m.def("radix_sort_pairs", &radix_sort_pairs, py::arg("keys"), py::arg("vals"), py::arg("n"), py::arg("bits"));
+    m.def("exclusive_scan", &exclusive_scan, py::arg("inp"), py::arg("out"), py::arg("n"));
+    py::class_<WinAggPipeline>(m, "WinAggPipeline")
+        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"),
+             py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"), py::arg("time_based") = false, py::arg("delay") = 0,
+             py::arg("inflight") = 6)
+        .def("step", &WinAggPipeline::step)
+        .def("close", &WinAggPipeline::close)
+        .def("stats", &WinAggPipeline::stats)
+        .def("reset_latency", &WinAggPipeline::reset_latency)
+        .def("dot", &WinAggPipeline::dot);
     py::class_<MapFilterPipeline>(m, "MapFilterPipeline")
         .def(py::init<int, size_t, size_t, size_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"),
              py::arg("inflight") = 6)

@@ -1,0 +1,479 @@
+// Key_FFAT_GPU: keyed sliding-window aggregation (lift + combine) with every
+// piece of keyed state resident in HBM.
+//
+// Capability parity with /root/reference/wf/key_ffat_gpu.hpp:68-247 +
+// wf/win_seqffat_gpu.hpp:56-698 + wf/flatfat_gpu.hpp (count- and time-based
+// sliding windows, quantum = gcd(win, slide) panes for time-based windows,
+// triggering delay, late tuples dropped, incomplete windows emitted at
+// end-of-stream).  Design is ours:
+//  * the reference does the windowing bookkeeping per tuple on the host, keeps one
+//    cudaMalloc'ed tree per key and launches kernels per key; here a whole
+//    mixed-key batch is processed on the device:
+//      1. assign_slots_kernel   key -> slot through a device hash table
+//      2. RadixSorter           stable sort of (slot, tuple index): the tuples of a
+//                               key become one contiguous run in arrival order
+//      3. ffat_update_kernel    one thread per run: lift, fold into panes, insert
+//                               completed panes into the key's FlatFAT (a slab of
+//                               trees in HBM), fire windows with an O(log n) ordered
+//                               range query, append results to the output batch
+//    so the number of launches per batch is constant whatever the number of keys,
+//    and state for millions of keys stays on the device (288 GB HBM3E).
+//  * lift and combine must both be device-callable (the reference lifts on the
+//    host because its tuples arrive one by one on the host).
+//  * end-of-stream runs ffat_flush_kernel on the device (the reference falls back
+//    to the CPU: win_seqffat_gpu.hpp:543-660).
+#pragma once
+#include <numeric>
+
+#include "batch_ops.hpp"
+#include "flatfat_gpu.hpp"
+#include "primitives.hpp"
+
+namespace wf {
+namespace gpu {
+
+struct FFATGeometry {
+    uint32_t is_tb;       // 1: time-based
+    uint64_t pane_len;    // CB: tuples per pane; TB: quantum (time units)
+    uint32_t win_panes;   // panes per window
+    uint32_t slide_panes; // panes per slide
+    uint64_t delay;       // TB triggering delay
+    uint32_t tree_cap;    // leaves per tree (power of two > win_panes)
+    uint32_t acc_cap;     // TB: open quanta ring (power of two)
+    uint32_t out_cap;     // capacity of the output batch
+};
+
+template <typename R>
+struct FFATKeyState {
+    uint64_t panes;         // completed panes inserted so far
+    uint64_t next_lwid;     // next window to fire
+    uint64_t last_quantum;  // TB: oldest open quantum
+    uint64_t max_quantum;   // TB: greatest quantum that received a tuple (+1), 0 = none
+    uint32_t pcount;        // CB: tuples in the open pane
+    uint32_t seen;          // key has received at least one tuple
+    R partial;              // CB: aggregate of the open pane
+};
+
+struct FFATCounters {
+    uint32_t dropped;          // late tuples
+    uint32_t overflow;         // results that did not fit the output batch
+    uint32_t skipped_windows;  // TB: empty windows skipped by a time jump beyond the tree capacity
+    uint32_t table_full;       // tuples whose key could not be inserted
+};
+
+template <typename R>
+__device__ __forceinline__ void ffat_emit(R* out, uint32_t* out_count, const FFATGeometry& g, FFATCounters* ctr, const R& r) {
+    const uint32_t pos = atomicAdd(out_count, 1u);
+    if (pos < g.out_cap)
+        out[pos] = r;
+    else
+        atomicAdd(&ctr->overflow, 1u);
+}
+
+// a pane is complete: insert it in the key's tree and fire the window it closes (if any)
+template <typename R, typename C, typename K>
+__device__ __forceinline__ void ffat_complete_pane(FFATKeyState<R>& st, R* tree, const FFATGeometry& g, const K& key, const R& pane, const C& comb,
+                                                   R* out, uint32_t* out_count, FFATCounters* ctr) {
+    fat_insert(tree, g.tree_cap, (uint32_t)(st.panes & (g.tree_cap - 1)), pane, comb);
+    st.panes++;
+    if (st.panes >= g.win_panes && (st.panes - g.win_panes) % g.slide_panes == 0) {
+        R res;
+        fat_query_circular(tree, g.tree_cap, (uint32_t)((st.panes - g.win_panes) & (g.tree_cap - 1)), g.win_panes, res, comb);
+        res.setControlFields(key, st.next_lwid, cf_ts(res));
+        st.next_lwid++;
+        ffat_emit(out, out_count, g, ctr, res);
+    }
+}
+
+// one thread per run of equal slots in the sorted (slot, index) arrays
+template <typename T, typename R, typename L, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_update_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
+                       R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, L lift, C comb) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = sslot[i];
+        if (i > 0 && sslot[i - 1] == slot) continue;  // not the head of a run
+        if (slot == 0xffffffffu) {
+            atomicAdd(&ctr->table_full, 1u);
+            continue;
+        }
+        FFATKeyState<R> st = states[slot];
+        R* tree = trees + (size_t)slot * 2 * g.tree_cap;
+        R* acc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
+        uint8_t* used = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
+        for (uint32_t j = i; j < n && sslot[j] == slot; j++) {
+            const T t = data[sidx[j]];
+            const auto key = cf_key(t);
+            const uint64_t ts = cf_ts(t);
+            st.seen = 1;
+            R lifted{};
+            lifted.setControlFields(key, 0, ts);
+            lift(t, lifted);
+            if (!g.is_tb) {
+                if (st.pcount == 0) {
+                    st.partial = lifted;
+                } else {
+                    R tmp;
+                    fat_combine(comb, st.partial, lifted, tmp);
+                    st.partial = tmp;
+                }
+                st.pcount++;
+                if (st.pcount == g.pane_len) {
+                    ffat_complete_pane(st, tree, g, key, st.partial, comb, out, out_count, ctr);
+                    st.pcount = 0;
+                }
+            } else {
+                const uint64_t q = ts / g.pane_len;
+                if (q < st.last_quantum) {
+                    atomicAdd(&ctr->dropped, 1u);
+                    continue;
+                }
+                // quanta whose last instant + delay is older than ts are complete
+                uint64_t done_upto = (ts > g.delay) ? (ts - g.delay) / g.pane_len : 0;  // quanta < done_upto are complete
+                // the ring of open quanta must be able to hold q
+                if (q >= done_upto + g.acc_cap) done_upto = q - g.acc_cap + 1;
+                if (done_upto > st.last_quantum) {
+                    auto complete_until = [&](uint64_t upto) {
+                        while (st.last_quantum < upto) {
+                            const uint32_t a = (uint32_t)(st.last_quantum & (g.acc_cap - 1));
+                            R pane{};
+                            if (used[a]) {
+                                pane = acc[a];
+                                used[a] = 0;
+                            }
+                            pane.setControlFields(key, st.last_quantum, (st.last_quantum + 1) * g.pane_len - 1);
+                            ffat_complete_pane(st, tree, g, key, pane, comb, out, out_count, ctr);
+                            st.last_quantum++;
+                        }
+                    };
+                    // A time jump much longer than the tree: flush the quanta that can hold data
+                    // (and the windows containing them), then fast-forward over the stretch in
+                    // which every window is empty instead of materialising each of them.
+                    const uint64_t keep = (uint64_t)g.tree_cap + g.acc_cap;
+                    if (done_upto - st.last_quantum > 4 * keep) {
+                        complete_until(st.last_quantum + keep);
+                        const uint64_t skip = done_upto - keep - st.last_quantum;
+                        const uint64_t panes_after = st.panes + skip;
+                        const uint64_t fired_after = panes_after >= g.win_panes ? (panes_after - g.win_panes) / g.slide_panes + 1 : 0;
+                        if (fired_after > st.next_lwid) {
+                            atomicAdd(&ctr->skipped_windows, (uint32_t)(fired_after - st.next_lwid));
+                            st.next_lwid = fired_after;
+                        }
+                        st.panes = panes_after;
+                        st.last_quantum += skip;
+                    }
+                    complete_until(done_upto);
+                }
+                const uint32_t a = (uint32_t)(q & (g.acc_cap - 1));
+                if (used[a]) {
+                    R tmp;
+                    fat_combine(comb, acc[a], lifted, tmp);
+                    acc[a] = tmp;
+                } else {
+                    acc[a] = lifted;
+                    used[a] = 1;
+                }
+                if (q + 1 > st.max_quantum) st.max_quantum = q + 1;
+            }
+        }
+        states[slot] = st;
+    }
+}
+
+// end of stream: one thread per table slot; completes what is open and emits the
+// remaining (incomplete) windows, as the CPU engine does (win_seqffat.hpp flush)
+template <typename R, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_flush_kernel(const unsigned long long* table, uint32_t table_cap, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
+                      FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, C comb) {
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < table_cap; slot += gridDim.x * blockDim.x) {
+        if (table[slot] == KEY_EMPTY) continue;
+        FFATKeyState<R> st = states[slot];
+        if (!st.seen) continue;
+        R* tree = trees + (size_t)slot * 2 * g.tree_cap;
+        // keys are stored as 64-bit values in the table
+        const auto key = (decltype(cf_key(st.partial)))table[slot];
+        if (!g.is_tb) {
+            if (st.pcount > 0) {
+                ffat_complete_pane(st, tree, g, key, st.partial, comb, out, out_count, ctr);
+                st.pcount = 0;
+            }
+        } else {
+            R* acc = accs + (size_t)slot * g.acc_cap;
+            uint8_t* used = acc_used + (size_t)slot * g.acc_cap;
+            while (st.last_quantum < st.max_quantum) {
+                const uint32_t a = (uint32_t)(st.last_quantum & (g.acc_cap - 1));
+                R pane{};
+                if (used[a]) {
+                    pane = acc[a];
+                    used[a] = 0;
+                }
+                pane.setControlFields(key, st.last_quantum, (st.last_quantum + 1) * g.pane_len - 1);
+                ffat_complete_pane(st, tree, g, key, pane, comb, out, out_count, ctr);
+                st.last_quantum++;
+            }
+        }
+        // incomplete windows: window lwid covers panes [lwid*slide_panes, +win_panes)
+        while (st.next_lwid * g.slide_panes < st.panes) {
+            const uint64_t first = st.next_lwid * g.slide_panes;
+            const uint32_t cnt = (uint32_t)(st.panes - first);
+            R res;
+            fat_query_circular(tree, g.tree_cap, (uint32_t)(first & (g.tree_cap - 1)), cnt < g.win_panes ? cnt : g.win_panes, res, comb);
+            res.setControlFields(key, st.next_lwid, cf_ts(res));
+            st.next_lwid++;
+            ffat_emit(out, out_count, g, ctr, res);
+        }
+        states[slot] = st;
+    }
+}
+
+// clamp the result count to the capacity and mirror it for the host
+__global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatile uint32_t* mirror) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t c = out_hdr->count;
+        if (c > cap) c = cap;
+        out_hdr->count = c;
+        *mirror = c;
+    }
+}
+
+struct KeyOfTuple {
+    template <typename T>
+    __host__ __device__ uint64_t operator()(const T& t) const {
+        return (uint64_t)cf_key(t);
+    }
+};
+
+// The engine proper: owns the device state, processes device batches of tuples and
+// produces device batches of results.  Single stream, not thread safe.
+template <typename T, typename R, typename L, typename C>
+class KeyedFFATEngine {
+public:
+    KeyedFFATEngine(L lift, C comb, uint64_t win, uint64_t slide, uint64_t delay, win_type_t type, size_t max_keys, size_t batch_capacity,
+                    size_t out_capacity, int device, size_t pool_slabs)
+        : lift_(lift), comb_(comb), device_(device) {
+        if (win == 0 || slide == 0) failwith("Key_FFAT_GPU: window length or slide cannot be zero");
+        if (slide >= win) failwith("Key_FFAT_GPU can be used with sliding windows only (s<w)");
+        const uint64_t pane = std::gcd(win, slide);
+        g_.is_tb = (type == TB);
+        g_.pane_len = pane;
+        g_.win_panes = (uint32_t)(win / pane);
+        g_.slide_panes = (uint32_t)(slide / pane);
+        g_.delay = delay;
+        uint32_t cap = 2;
+        while (cap <= g_.win_panes) cap <<= 1;
+        g_.tree_cap = cap;
+        uint32_t acc = 2;
+        const uint64_t need = (type == TB) ? delay / pane + 2 : 1;
+        while (acc < need) acc <<= 1;
+        g_.acc_cap = acc;
+        g_.out_cap = (uint32_t)out_capacity;
+        table_cap_ = 2;
+        while (table_cap_ < 2 * max_keys) table_cap_ <<= 1;
+        slot_bits_ = 0;
+        while ((1ull << slot_bits_) < table_cap_) slot_bits_++;
+        batch_cap_ = batch_capacity;
+        WF_HIP_CHECK(hipSetDevice(device_));
+        table_.resize(table_cap_);
+        WF_HIP_CHECK(hipMemset(table_.data(), 0xff, table_cap_ * sizeof(unsigned long long)));
+        states_.resize(table_cap_);
+        WF_HIP_CHECK(hipMemset(states_.data(), 0, table_cap_ * sizeof(FFATKeyState<R>)));
+        trees_.resize((size_t)table_cap_ * 2 * g_.tree_cap);
+        WF_HIP_CHECK(hipMemset(trees_.data(), 0, trees_.bytes()));
+        if (g_.is_tb) {
+            accs_.resize((size_t)table_cap_ * g_.acc_cap);
+            WF_HIP_CHECK(hipMemset(accs_.data(), 0, accs_.bytes()));
+            acc_used_.resize((size_t)table_cap_ * g_.acc_cap);
+            WF_HIP_CHECK(hipMemset(acc_used_.data(), 0, acc_used_.bytes()));
+        }
+        slot_.resize(batch_cap_);
+        idx_.resize(batch_cap_);
+        counters_.resize(1);
+        WF_HIP_CHECK(hipMemset(counters_.data(), 0, sizeof(FFATCounters)));
+        sorter_.reserve(batch_cap_);
+        out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), out_capacity, pool_slabs));
+    }
+
+    const FFATGeometry& geometry() const { return g_; }
+    size_t device_bytes() const { return table_.bytes() + states_.bytes() + trees_.bytes() + accs_.bytes() + acc_used_.bytes(); }
+
+    // enqueue the processing of `in` on `s`; returns the batch of fired windows (count on device)
+    Batch* process(Batch* in, hipStream_t s, uint64_t& kernels) {
+        const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
+        if (upper > batch_cap_) failwith("Key_FFAT_GPU: input batch larger than the configured batch capacity");
+        Batch* out = out_pool_->acquire(s);
+        out->host_hdr = in->host_hdr;
+        out->count_on_host = false;
+        WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
+        if (upper > 0) {
+            const unsigned grid = grid_for(upper);
+            hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{});
+            sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+            hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                               slot_.data(), idx_.data(), states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
+                               out->template data<R>(), out->device_count_ptr(), counters_.data(), lift_, comb_);
+            kernels += 2 + sorter_.kernels_per_sort(slot_bits_ + 1);
+        }
+        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
+        kernels++;
+        return out;
+    }
+
+    // end of stream: emit every incomplete window; may need several output batches
+    Batch* flush(hipStream_t s, uint64_t& kernels) {
+        Batch* out = out_pool_->acquire(s);
+        out->host_hdr = BatchHeader{};
+        out->count_on_host = false;
+        WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
+        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(table_cap_)), dim3(BLOCK_THREADS), 0, s, table_.data(), (uint32_t)table_cap_,
+                           states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_, out->template data<R>(), out->device_count_ptr(),
+                           counters_.data(), comb_);
+        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
+        kernels += 2;
+        return out;
+    }
+
+    FFATCounters read_counters(hipStream_t s) {
+        FFATCounters c{};
+        WF_HIP_CHECK(hipMemcpyAsync(&c, counters_.data(), sizeof(c), hipMemcpyDeviceToHost, s));
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+        return c;
+    }
+
+private:
+    L lift_;
+    C comb_;
+    int device_;
+    FFATGeometry g_{};
+    size_t table_cap_ = 0, batch_cap_ = 0;
+    int slot_bits_ = 0;
+    DeviceBuffer<unsigned long long> table_;
+    DeviceBuffer<FFATKeyState<R>> states_;
+    DeviceBuffer<R> trees_;
+    DeviceBuffer<R> accs_;
+    DeviceBuffer<uint8_t> acc_used_;
+    DeviceBuffer<uint32_t> slot_, idx_;
+    DeviceBuffer<FFATCounters> counters_;
+    RadixSorter sorter_;
+    std::unique_ptr<BatchPool> out_pool_;
+};
+
+}  // namespace gpu
+
+// ---- operator ------------------------------------------------------------------
+struct KeyFFATGPUConfig {
+    uint64_t win_len = 2, slide_len = 1, delay = 0;
+    win_type_t type = CB;
+    size_t max_keys = 1 << 16;   // distinct keys per replica the device table is sized for
+    size_t out_capacity = 0;     // results per output batch (0: same as the input batch capacity)
+};
+
+template <typename tuple_t, typename result_t, typename L, typename C>
+class KeyFFATGPU_Node : public GPU_Replica<tuple_t> {
+public:
+    KeyFFATGPU_Node(L lift, C comb, KeyFFATGPUConfig wcfg, GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx,
+                    meta::closing_func_t closing, std::shared_ptr<StatsHub> hub, std::shared_ptr<std::vector<gpu::FFATCounters>> counters)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub), true), lift_(lift), comb_(comb),
+          wcfg_(wcfg), counters_(std::move(counters)) {}
+
+protected:
+    void process_device(gpu::Batch* d) override {
+        if (!engine_) {
+            const size_t out_cap = wcfg_.out_capacity ? wcfg_.out_capacity : d->capacity;
+            engine_.reset(new gpu::KeyedFFATEngine<tuple_t, result_t, L, C>(lift_, comb_, wcfg_.win_len, wcfg_.slide_len, wcfg_.delay, wcfg_.type,
+                                                                            wcfg_.max_keys, d->capacity, out_cap, this->cfg_.gpu_id,
+                                                                            this->cfg_.pool_slabs));
+        }
+        gpu::Batch* out = engine_->process(d, this->stream(), this->num_kernels_);
+        d->release(this->stream());
+        this->emit_device(out);
+    }
+    void gpu_flush() override {
+        if (!engine_) return;
+        gpu::Batch* out = engine_->flush(this->stream(), this->num_kernels_);
+        this->emit_device(out);
+        if (counters_) (*counters_)[this->context.getReplicaIndex()] = engine_->read_counters(this->stream());
+    }
+
+private:
+    L lift_;
+    C comb_;
+    KeyFFATGPUConfig wcfg_;
+    std::shared_ptr<std::vector<gpu::FFATCounters>> counters_;
+    std::unique_ptr<gpu::KeyedFFATEngine<tuple_t, result_t, L, C>> engine_;
+};
+
+// Keyed operator.  With tuple input the MultiPipe routes by key on the host
+// (KF_Emitter) and every replica batches its own keys; with batch input replica i
+// consumes lane i directly, so the producer lanes must carry disjoint key sets
+// (true by construction after a KeyBy exchange or a key-partitioned source).
+template <typename tuple_t, typename result_t>
+class Key_FFAT_GPU : public Basic_Operator {
+public:
+    template <typename L, typename C>
+    Key_FFAT_GPU(L lift, C comb, KeyFFATGPUConfig wcfg, size_t parallelism, std::string name, GPUConfig cfg = GPUConfig(),
+                 meta::closing_func_t closing = nullptr, routing_func_t routing = default_routing)
+        : name_(std::move(name)), par_(parallelism), wcfg_(wcfg), routing_(std::move(routing)), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)),
+          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)) {
+        if (par_ == 0) fatal_error("Key_FFAT_GPU has parallelism zero");
+        auto hub = hub_;
+        auto kind = kind_;
+        auto counters = counters_;
+        const std::string n = name_;
+        const size_t N = par_;
+        factory_ = [=](rt::Graph& g) {
+            std::vector<rt::Node*> reps;
+            for (size_t i = 0; i < N; i++)
+                reps.push_back(g.adopt(new KeyFFATGPU_Node<tuple_t, result_t, L, C>(lift, comb, wcfg, cfg, *kind, n, N, i, closing, hub, counters)));
+            return reps;
+        };
+    }
+    std::string getName() const override { return name_; }
+    size_t getParallelism() const override { return par_; }
+    routing_modes_t getRoutingMode() const override { return *kind_ == EDGE_TUPLE ? COMPLEX : FORWARD; }
+    bool isWindowed() const override { return true; }
+    bool isGPUOperator() const override { return true; }
+    const std::type_info& input_type() const override { return typeid(tuple_t); }
+    const std::type_info& output_type() const override { return typeid(result_t); }
+    edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
+    bool accepts_input_kind(edge_kind_t) const override { return true; }
+    void set_input_kind(edge_kind_t k) override { *kind_ = k; }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(); }
+    // per-replica device counters, valid after the end of the run
+    std::vector<gpu::FFATCounters> getDeviceCounters() const { return *counters_; }
+
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
+        StageSpec s;
+        s.name = name_;
+        s.replicas = factory_(g);
+        const size_t N = par_;
+        if (*kind_ == EDGE_TUPLE) {
+            s.routing = COMPLEX;
+            routing_func_t rf = routing_;
+            s.make_emitter = [rf, N](rt::Graph& gr, size_t) { return single_emitter(gr, new KF_Emitter<tuple_t>(rf, N), N); };
+            const win_type_t type = wcfg_.type;
+            s.make_ordering = [type](Mode m) -> rt::Node* {
+                // count-based windows count arrivals per key on the device: only the order matters
+                if (m == Mode::DETERMINISTIC) return new Ordering_Node<tuple_t>(type == CB ? TS_RENUMBERING : TS);
+                return nullptr;
+            };
+        } else {
+            s.routing = FORWARD;  // lane i -> replica i, or round-robin when parallelism differs
+            s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
+        }
+        return {s};
+    }
+
+private:
+    std::string name_;
+    size_t par_;
+    KeyFFATGPUConfig wcfg_;
+    routing_func_t routing_;
+    std::shared_ptr<edge_kind_t> kind_;
+    std::shared_ptr<std::vector<gpu::FFATCounters>> counters_;
+    std::function<std::vector<rt::Node*>(rt::Graph&)> factory_;
+};
+
+}  // namespace wf

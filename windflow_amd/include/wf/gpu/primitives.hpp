@@ -1,0 +1,351 @@
+// Device primitives shared by the keyed GPU operators: single-pass exclusive
+// scan, key -> slot hash table, stable LSD radix sort of (slot, index) pairs and
+// one-pass multi-way partition.
+//
+// What they replace in the reference:
+//   K12 map_to_target / prescan / gather_sums + host recursion with
+//       cudaDeviceSynchronize (wf/gpu_utils.hpp:322-401)     -> exclusive_scan_u32
+//   K13 create_sub_batch, one scan+scatter pass per destination
+//       (wf/standard_nodes_gpu.hpp:52-58, :172-212)           -> partition_by_dest
+//   B11 Thrust sort_by_key / reduce_by_key key scatter
+//       (src/GPU_Tests/scattering/test_v4.cpp:244-293)        -> radix_sort_pairs
+//   host-built per-key linked lists of the stateful benchmarks
+//       (gpu_map_stateful.cpp:311-328)                        -> DeviceKeyTable + sort
+// All kernels are wave64: in-wave ranks come from __ballot + popcount, per-wave
+// totals are combined through LDS, cross-tile offsets through decoupled look-back
+// (scan) or a digit-major histogram scan (sort / partition).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "hip_utils.hpp"
+#include "kernels_basic.hpp"
+
+namespace wf {
+namespace gpu {
+
+// ---------------------------------------------------------------------------
+// exclusive scan of uint32 (single pass, decoupled look-back)
+// ws: [0] ticket, [1..] descriptors; must be zeroed before the launch
+// ---------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK_THREADS * SCAN_ITEMS;
+inline size_t scan_workspace_words(size_t n) { return 2 + (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o, WAVE);
+        if (lane_id() >= o) v += u;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    exclusive_scan_u32_kernel(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total, unsigned long long* ws) {
+    __shared__ uint32_t s_wave[BLOCK_THREADS / WAVE];
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(&ws[0], 1ull);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tile >= n_tiles) {
+        if (n_tiles == 0 && tile == 0 && threadIdx.x == 0 && total) *total = 0;
+        return;
+    }
+    unsigned long long* desc = ws + 1;
+    const int lane = lane_id(), wave = wave_id();
+    // blocked arrangement: thread t owns SCAN_ITEMS consecutive elements
+    const uint32_t base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if (lane == WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK_THREADS / WAVE; w++) {
+        if (w < wave) wave_off += s_wave[w];
+        tile_total += s_wave[w];
+    }
+    if (wave == 0) {
+        uint32_t exclusive = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&desc[0], DESC_INC | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&desc[tile], DESC_AGG | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)tile - 1;
+            while (true) {
+                const int p = look - lane;
+                unsigned long long d = DESC_INC;
+                if (p >= 0) {
+                    do {
+                        d = __hip_atomic_load(&desc[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((d >> 32) == 0);
+                }
+                const unsigned long long inc_mask = __ballot((d >> 32) == 2);
+                const int stop = inc_mask ? (int)__builtin_ctzll(inc_mask) : WAVE;
+                uint32_t x = (lane <= stop) ? (uint32_t)(d & 0xffffffffu) : 0u;
+#pragma unroll
+                for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+                exclusive += x;
+                if (inc_mask) break;
+                look -= WAVE;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&desc[tile], DESC_INC | (unsigned long long)(exclusive + tile_total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = exclusive;
+            if (tile == n_tiles - 1 && total) *total = exclusive + tile_total;
+        }
+    }
+    __syncthreads();
+    uint32_t run = s_base + wave_off + (inc - sum);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+inline void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, unsigned long long* ws, hipStream_t s) {
+    WF_HIP_CHECK(hipMemsetAsync(ws, 0, scan_workspace_words(n) * sizeof(unsigned long long), s));
+    const unsigned grid = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(exclusive_scan_u32_kernel, dim3(grid ? grid : 1), dim3(BLOCK_THREADS), 0, s, in, out, (uint32_t)n, total, ws);
+}
+
+// ---------------------------------------------------------------------------
+// key -> slot table (open addressing, linear probing, insert-or-find)
+// ---------------------------------------------------------------------------
+constexpr unsigned long long KEY_EMPTY = ~0ull;
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+// returns the slot (table position) of `key`, inserting it if absent; 0xffffffff if full
+__device__ __forceinline__ uint32_t key_table_slot(unsigned long long* table, uint32_t mask, unsigned long long key) {
+    uint32_t h = (uint32_t)mix64(key) & mask;
+    for (uint32_t probes = 0; probes <= mask; probes++) {
+        unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return h;
+        if (cur == KEY_EMPTY) {
+            const unsigned long long prev = atomicCAS(&table[h], KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+    return 0xffffffffu;
+}
+
+// slot[i] = slot of tuple i's key; idx[i] = i.  KeyFn: uint64_t(const T&)
+template <typename T, typename KeyFn>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    assign_slots_kernel(const BatchHeader* hdr, const T* data, unsigned long long* table, uint32_t mask, uint32_t* slot, uint32_t* idx,
+                        uint32_t* n_failed, KeyFn keyfn) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = key_table_slot(table, mask, (unsigned long long)keyfn(data[i]));
+        if (s == 0xffffffffu) atomicAdd(n_failed, 1u);
+        slot[i] = s;
+        idx[i] = i;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stable LSD radix sort of (key32, value32) pairs, 8 bits per pass
+// ---------------------------------------------------------------------------
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = BLOCK_THREADS * RS_ITEMS;  // 2048 pairs per block
+constexpr int RS_BINS = 256;
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    radix_hist_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/) {
+    __shared__ uint32_t s_hist[RS_BINS];
+    const uint32_t n = *n_ptr;
+    const uint32_t tile = blockIdx.x;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = tile * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = base + k * BLOCK_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + tile] = s_hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    radix_scatter_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
+                         uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive*/) {
+    constexpr int NW = BLOCK_THREADS / WAVE;
+    __shared__ uint32_t s_cnt[RS_ITEMS * NW][RS_BINS];  // per (item round, wave) digit counts -> 32 KiB
+    const uint32_t n = *n_ptr;
+    const uint32_t tile = blockIdx.x;
+    const int lane = lane_id(), wave = wave_id();
+    for (int r = 0; r < RS_ITEMS * NW; r++) s_cnt[r][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = tile * RS_TILE;
+    uint32_t k_[RS_ITEMS], v_[RS_ITEMS], rank[RS_ITEMS];
+    bool ok[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = base + k * BLOCK_THREADS + threadIdx.x;
+        ok[k] = i < n;
+        k_[k] = ok[k] ? keys_in[i] : 0xffffffffu;
+        v_[k] = ok[k] ? vals_in[i] : 0u;
+        const uint32_t digit = (k_[k] >> shift) & 0xff;
+        // lanes of this wave holding the same digit (match-any with 8 ballots)
+        unsigned long long m = __ballot(ok[k]);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long bal = __ballot((digit >> b) & 1);
+            m &= ((digit >> b) & 1) ? bal : ~bal;
+        }
+        rank[k] = (uint32_t)__popcll(m & lanemask_lt());
+        if (ok[k] && rank[k] == 0) s_cnt[k * NW + wave][digit] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // per digit (one thread per digit): exclusive prefix over the (round, wave) sequence + global base
+    {
+        uint32_t run = hist_scanned[threadIdx.x * n_tiles + tile];
+        for (int r = 0; r < RS_ITEMS * NW; r++) {
+            const uint32_t c = s_cnt[r][threadIdx.x];
+            s_cnt[r][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        if (ok[k]) {
+            const uint32_t digit = (k_[k] >> shift) & 0xff;
+            const uint32_t dst = s_cnt[k * NW + wave][digit] + rank[k];
+            keys_out[dst] = k_[k];
+            vals_out[dst] = v_[k];
+        }
+    }
+    (void)lane;
+}
+
+// scan of the digit-major histogram: one block, serial over chunks (the array has
+// 256 * n_tiles entries; n_tiles <= a few thousand)
+__global__ void __launch_bounds__(1024) radix_hist_scan_kernel(uint32_t* hist, uint32_t total_entries) {
+    __shared__ uint32_t s_wave[1024 / WAVE];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    for (uint32_t base = 0; base < total_entries; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < total_entries) ? hist[i] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (lane == WAVE - 1) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (i < total_entries) hist[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+}
+
+// Workspace + driver for sorting up to `capacity` pairs.  `bits` = number of
+// significant key bits (passes = ceil(bits/8)).  n is read from device memory so a
+// data-dependent count never has to come back to the host.
+class RadixSorter {
+public:
+    void reserve(size_t capacity) {
+        if (capacity <= cap_) return;
+        cap_ = capacity;
+        tiles_ = (capacity + RS_TILE - 1) / RS_TILE;
+        keys_tmp_.resize(capacity);
+        vals_tmp_.resize(capacity);
+        hist_.resize((size_t)RS_BINS * tiles_);
+    }
+    // sorts (keys, vals) in place (ping-pong through internal buffers); n_upper bounds the grid
+    void sort(uint32_t* keys, uint32_t* vals, const uint32_t* n_dev, size_t n_upper, int bits, hipStream_t s) {
+        reserve(n_upper);
+        const uint32_t tiles = (uint32_t)((n_upper + RS_TILE - 1) / RS_TILE);
+        if (tiles == 0) return;
+        uint32_t* kin = keys;
+        uint32_t* vin = vals;
+        uint32_t* kout = keys_tmp_.data();
+        uint32_t* vout = vals_tmp_.data();
+        int passes = (bits + 7) / 8;
+        if (passes < 1) passes = 1;
+        for (int p = 0; p < passes; p++) {
+            const int shift = 8 * p;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
+            hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(1), dim3(1024), 0, s, hist_.data(), (uint32_t)(RS_BINS * tiles));
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
+                               hist_.data());
+            std::swap(kin, kout);
+            std::swap(vin, vout);
+        }
+        if (kin != keys) {  // odd number of passes: results live in the temporaries
+            WF_HIP_CHECK(hipMemcpyAsync(keys, kin, n_upper * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            WF_HIP_CHECK(hipMemcpyAsync(vals, vin, n_upper * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    int kernels_per_sort(int bits) const { return 3 * std::max(1, (bits + 7) / 8); }
+
+private:
+    size_t cap_ = 0, tiles_ = 0;
+    DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_;
+};
+
+// ---------------------------------------------------------------------------
+// one-pass multi-way partition of a tuple batch by destination (K13):
+// dest = routing(hash(key)) in [0, P), P <= 256.  Produces the tuples grouped by
+// destination in stable order plus the P+1 segment offsets - exactly the send
+// buffer / send counts of an all-to-all-v exchange.
+// ---------------------------------------------------------------------------
+template <typename T, typename KeyFn>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    dest_keys_kernel(const BatchHeader* hdr, const T* data, uint32_t n_dest, uint32_t* dest, uint32_t* idx, KeyFn keyfn) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        dest[i] = (uint32_t)(mix64((uint64_t)keyfn(data[i])) % n_dest);
+        idx[i] = i;
+    }
+}
+
+// gather tuples through a permutation; also derives the per-destination offsets
+// from the sorted destination array (offsets[d] = first position with dest >= d)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    gather_partition_kernel(const BatchHeader* hdr, const T* in, const uint32_t* sorted_dest, const uint32_t* perm, T* out, uint32_t n_dest,
+                            uint32_t* offsets /*[n_dest+1]*/) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        out[i] = in[perm[i]];
+        const uint32_t d = sorted_dest[i];
+        const uint32_t prev = (i == 0) ? 0u : sorted_dest[i - 1] + 1u;
+        // every destination in (prev_dest, d] starts here
+        for (uint32_t x = (i == 0 ? 0u : prev); x <= d; x++) offsets[x] = i;
+        if (i == n - 1)
+            for (uint32_t x = d + 1; x <= n_dest; x++) offsets[x] = n;
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint32_t x = 0; x <= n_dest; x++) offsets[x] = 0;
+}
+
+}  // namespace gpu
+}  // namespace wf

@@ -34,7 +34,7 @@ public:
     template <typename N>
     N* adopt(N* n) {
         nodes_.emplace_back(n);
-        n->cfg_ = &cfg_;
+        static_cast<Node*>(n)->cfg_ = &cfg_;
         return n;
     }
 

@@ -7,4 +7,7 @@
 #include "gpu/batch_ops.hpp"
 #include "gpu/map_gpu.hpp"
 #include "gpu/filter_gpu.hpp"
+#include "gpu/primitives.hpp"
+#include "gpu/flatfat_gpu.hpp"
+#include "gpu/key_ffat_gpu.hpp"
 #include "builders_gpu.hpp"
