@@ -32,10 +32,15 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "map_filter"))
+    p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "win_agg"),
+                   help="win_agg: keyed sliding-window aggregation (flagship); map_filter: stateless Map_GPU+Filter_GPU")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
     p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", str(256 * 1024))))
-    p.add_argument("--keys", type=int, default=int(os.environ.get("WF_BENCH_KEYS", "1000")))
+    p.add_argument("--keys", type=int, default=int(os.environ.get("WF_BENCH_KEYS", str(1 << 20))),
+                   help="distinct keys per GPU (all resident in HBM)")
+    p.add_argument("--win", type=int, default=16, help="window length, in tuples of one key")
+    p.add_argument("--slide", type=int, default=4, help="window slide, in tuples of one key")
+    p.add_argument("--count-based", action="store_true", help="count-based instead of time-based windows")
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
                    help="tuples fed per GPU per step")
     p.add_argument("--inflight", type=int, default=6)
@@ -59,8 +64,16 @@ def main():
     ext = windflow_amd.load_ext()
     per_source = max(1, args.tuples_per_step // args.sources)
     tuples_per_step_gpu = per_source * args.sources
+    keys_per_source = max(1, args.keys // args.sources)
     if args.pipeline == "map_filter":
-        pipe = ext.MapFilterPipeline(local_rank, args.sources, args.batch, args.keys, args.inflight)
+        pipe = ext.MapFilterPipeline(local_rank, args.sources, args.batch, keys_per_source, args.inflight)
+    elif args.pipeline == "win_agg":
+        if args.count_based:
+            win, slide = args.win, args.slide
+        else:
+            # one tuple per microsecond per source, keys round-robin: a key ticks every keys_per_source us
+            win, slide = args.win * keys_per_source, args.slide * keys_per_source
+        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0, args.inflight)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 
@@ -108,13 +121,16 @@ def main():
             "p99_latency_us": float(lat.item()),
             "p50_latency_us": stats["latency_p50_us"],
             "config": {
-                "model": args.pipeline,
+                "model": "Key_FFAT_GPU keyed sliding-window sum" if args.pipeline == "win_agg" else args.pipeline,
                 "global_batch": tuples_per_step_gpu * world,
                 "seq_len": args.batch,
                 "parallelism": "dp%d" % world,
                 "sources_per_gpu": args.sources,
-                "keys": args.keys,
-                "sink_tuples_rank0": stats["sink_tuples"],
+                "keys_per_gpu": keys_per_source * args.sources,
+                "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if args.count_based else "TB", args.win, args.slide),
+                "sink_results_rank0": stats["sink_tuples"],
+                "overflow": stats.get("overflow", 0),
+                "dropped": stats.get("dropped", 0),
             },
         }), flush=True)
     if world > 1:

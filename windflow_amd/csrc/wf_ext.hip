@@ -216,7 +216,11 @@ static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::arra
         d->release(stream);
         drain(out);
     }
-    drain(engine.flush(stream, kernels));
+    {
+        size_t cursor = 0;
+        gpu::Batch* out = nullptr;
+        while (engine.flush_range(cursor, stream, kernels, out)) drain(out);
+    }
     gpu::FFATCounters c = engine.read_counters(stream);
     py::array_t<int64_t> arr({(py::ssize_t)results.size(), (py::ssize_t)4});
     if (!results.empty()) std::memcpy(arr.mutable_data(), results.data(), results.size() * sizeof(result_t));

@@ -160,10 +160,14 @@ private:
     std::deque<InFlight> fifo_;
 };
 
+// `producer_slabs` = size of the pool the device batches come from: the adapter
+// never holds more than producer_slabs - 1 of them, so the producer (which runs in
+// the same thread when fused) can always acquire one more
 template <typename T>
-inline std::function<rt::Node*(edge_kind_t)> batch_adapter_factory() {
-    return [](edge_kind_t from) -> rt::Node* {
-        if (from == EDGE_DEVICE_BATCH) return new DeviceToHost<T>();
+inline std::function<rt::Node*(edge_kind_t)> batch_adapter_factory(size_t producer_slabs = 6) {
+    const size_t depth = producer_slabs >= 3 ? std::min<size_t>(4, producer_slabs - 2) : 0;
+    return [depth](edge_kind_t from) -> rt::Node* {
+        if (from == EDGE_DEVICE_BATCH) return new DeviceToHost<T>(depth);
         return new Unbatcher<T>();
     };
 }

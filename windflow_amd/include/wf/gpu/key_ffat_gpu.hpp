@@ -85,6 +85,8 @@ __device__ __forceinline__ void ffat_complete_pane(FFATKeyState<R>& st, R* tree,
     }
 }
 
+constexpr int FFAT_PREFETCH = 4;
+
 // one thread per run of equal slots in the sorted (slot, index) arrays
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
@@ -102,8 +104,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         R* acc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
         uint8_t* used = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
-        for (uint32_t j = i; j < n && sslot[j] == slot; j++) {
-            const T t = data[sidx[j]];
+        // software prefetch: the tuples of a run are gathered FFAT_PREFETCH at a time so that
+        // their (dependent, random) loads are in flight together
+        bool run_open = true;
+        for (uint32_t j0 = i; run_open; j0 += FFAT_PREFETCH) {
+            T pre[FFAT_PREFETCH];
+            bool ok[FFAT_PREFETCH];
+#pragma unroll
+            for (int u = 0; u < FFAT_PREFETCH; u++) {
+                const uint32_t j = j0 + u;
+                ok[u] = (j < n) && (sslot[j] == slot);
+                if (ok[u]) pre[u] = data[sidx[j]];
+            }
+#pragma unroll
+            for (int u = 0; u < FFAT_PREFETCH; u++) {
+            if (!ok[u]) {
+                run_open = false;
+                break;
+            }
+            const T& t = pre[u];
             const auto key = cf_key(t);
             const uint64_t ts = cf_ts(t);
             st.seen = 1;
@@ -177,6 +196,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 if (q + 1 > st.max_quantum) st.max_quantum = q + 1;
             }
         }
+        }
         states[slot] = st;
     }
 }
@@ -185,9 +205,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 // remaining (incomplete) windows, as the CPU engine does (win_seqffat.hpp flush)
 template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_flush_kernel(const unsigned long long* table, uint32_t table_cap, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
+    ffat_flush_kernel(const unsigned long long* table, uint32_t slot_lo, uint32_t slot_hi, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
                       FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, C comb) {
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < table_cap; slot += gridDim.x * blockDim.x) {
+    for (uint32_t slot = slot_lo + blockIdx.x * blockDim.x + threadIdx.x; slot < slot_hi; slot += gridDim.x * blockDim.x) {
         if (table[slot] == KEY_EMPTY) continue;
         FFATKeyState<R> st = states[slot];
         if (!st.seen) continue;
@@ -321,18 +341,27 @@ public:
         return out;
     }
 
-    // end of stream: emit every incomplete window; may need several output batches
-    Batch* flush(hipStream_t s, uint64_t& kernels) {
-        Batch* out = out_pool_->acquire(s);
+    // end of stream: emit every incomplete window.  The table is flushed in slot
+    // ranges sized so that the windows of a range always fit one output batch;
+    // the caller hands each batch downstream before asking for the next one, so
+    // the bounded output pool never deadlocks.
+    // flush one slot range at a time (bounded number of output batches in flight)
+    bool flush_range(size_t& cursor, hipStream_t s, uint64_t& kernels, Batch*& out) {
+        if (cursor >= table_cap_) return false;
+        const size_t per_key = (size_t)g_.win_panes / g_.slide_panes + 2 + (g_.is_tb ? g_.acc_cap : 0);
+        const size_t slots_per_round = std::max<size_t>(1, g_.out_cap / per_key);
+        const size_t lo = cursor, hi = std::min(table_cap_, lo + slots_per_round);
+        cursor = hi;
+        out = out_pool_->acquire(s);
         out->host_hdr = BatchHeader{};
         out->count_on_host = false;
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
-        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(table_cap_)), dim3(BLOCK_THREADS), 0, s, table_.data(), (uint32_t)table_cap_,
+        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.data(), (uint32_t)lo, (uint32_t)hi,
                            states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_, out->template data<R>(), out->device_count_ptr(),
                            counters_.data(), comb_);
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
         kernels += 2;
-        return out;
+        return true;
     }
 
     FFATCounters read_counters(hipStream_t s) {
@@ -392,8 +421,9 @@ protected:
     }
     void gpu_flush() override {
         if (!engine_) return;
-        gpu::Batch* out = engine_->flush(this->stream(), this->num_kernels_);
-        this->emit_device(out);
+        size_t cursor = 0;
+        gpu::Batch* out = nullptr;
+        while (engine_->flush_range(cursor, this->stream(), this->num_kernels_, out)) this->emit_device(out);
         if (counters_) (*counters_)[this->context.getReplicaIndex()] = engine_->read_counters(this->stream());
     }
 
@@ -416,7 +446,7 @@ public:
     Key_FFAT_GPU(L lift, C comb, KeyFFATGPUConfig wcfg, size_t parallelism, std::string name, GPUConfig cfg = GPUConfig(),
                  meta::closing_func_t closing = nullptr, routing_func_t routing = default_routing)
         : name_(std::move(name)), par_(parallelism), wcfg_(wcfg), routing_(std::move(routing)), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)),
-          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)) {
+          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)), slabs_(cfg.pool_slabs) {
         if (par_ == 0) fatal_error("Key_FFAT_GPU has parallelism zero");
         auto hub = hub_;
         auto kind = kind_;
@@ -440,7 +470,7 @@ public:
     edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
     bool accepts_input_kind(edge_kind_t) const override { return true; }
     void set_input_kind(edge_kind_t k) override { *kind_ = k; }
-    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(); }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(slabs_); }
     // per-replica device counters, valid after the end of the run
     std::vector<gpu::FFATCounters> getDeviceCounters() const { return *counters_; }
 
@@ -473,6 +503,7 @@ private:
     routing_func_t routing_;
     std::shared_ptr<edge_kind_t> kind_;
     std::shared_ptr<std::vector<gpu::FFATCounters>> counters_;
+    size_t slabs_;
     std::function<std::vector<rt::Node*>(rt::Graph&)> factory_;
 };
 
