@@ -242,7 +242,11 @@ static void radix_sort_pairs(uintptr_t keys, uintptr_t vals, size_t n, int bits)
     const uint32_t n32 = (uint32_t)n;
     WF_HIP_CHECK(hipMemcpy(n_dev.data(), &n32, 4, hipMemcpyHostToDevice));
     gpu::RadixSorter sorter;
-    sorter.sort(reinterpret_cast<uint32_t*>(keys), reinterpret_cast<uint32_t*>(vals), n_dev.data(), n, bits, 0);
+    auto sorted = sorter.sort(reinterpret_cast<uint32_t*>(keys), reinterpret_cast<uint32_t*>(vals), n_dev.data(), n, bits, 0);
+    if (sorted.keys != reinterpret_cast<uint32_t*>(keys)) {
+        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(keys), sorted.keys, n * 4, hipMemcpyDeviceToDevice, 0));
+        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(vals), sorted.vals, n * 4, hipMemcpyDeviceToDevice, 0));
+    }
     WF_HIP_CHECK(hipGetLastError());
     WF_HIP_CHECK(hipDeviceSynchronize());
 }

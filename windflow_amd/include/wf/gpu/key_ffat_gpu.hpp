@@ -330,9 +330,9 @@ public:
             const unsigned grid = grid_for(upper);
             hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{});
-            sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+            const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               slot_.data(), idx_.data(), states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
+                               sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), lift_, comb_);
             kernels += 2 + sorter_.kernels_per_sort(slot_bits_ + 1);
         }

@@ -192,9 +192,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 __global__ void __launch_bounds__(BLOCK_THREADS)
     radix_scatter_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
-                         uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive*/) {
+                         uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
+                         const uint32_t* bin_totals /*[bin]*/) {
     constexpr int NW = BLOCK_THREADS / WAVE;
     __shared__ uint32_t s_cnt[RS_ITEMS * NW][RS_BINS];  // per (item round, wave) digit counts -> 32 KiB
+    __shared__ uint32_t s_bin_base[RS_BINS];
+    __shared__ uint32_t s_wsum[NW];
+    {
+        // exclusive scan of the 256 bin totals (one value per thread)
+        const uint32_t v = bin_totals[threadIdx.x];
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (lane_id() == WAVE - 1) s_wsum[wave_id()] = inc;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave_id(); w++) off += s_wsum[w];
+        s_bin_base[threadIdx.x] = off + inc - v;
+    }
     const uint32_t n = *n_ptr;
     const uint32_t tile = blockIdx.x;
     const int lane = lane_id(), wave = wave_id();
@@ -223,7 +236,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     __syncthreads();
     // per digit (one thread per digit): exclusive prefix over the (round, wave) sequence + global base
     {
-        uint32_t run = hist_scanned[threadIdx.x * n_tiles + tile];
+        uint32_t run = s_bin_base[threadIdx.x] + hist_scanned[threadIdx.x * n_tiles + tile];
         for (int r = 0; r < RS_ITEMS * NW; r++) {
             const uint32_t c = s_cnt[r][threadIdx.x];
             s_cnt[r][threadIdx.x] = run;
@@ -243,27 +256,30 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     (void)lane;
 }
 
-// scan of the digit-major histogram: one block, serial over chunks (the array has
-// 256 * n_tiles entries; n_tiles <= a few thousand)
-__global__ void __launch_bounds__(1024) radix_hist_scan_kernel(uint32_t* hist, uint32_t total_entries) {
-    __shared__ uint32_t s_wave[1024 / WAVE];
+// per-bin exclusive scan of the digit-major histogram: block b scans hist[b][0..n_tiles)
+// and publishes the bin total; the scatter kernel adds the prefix over bins itself.
+// (256 independent blocks instead of one serial block over 256*n_tiles entries.)
+__global__ void __launch_bounds__(BLOCK_THREADS) radix_bin_scan_kernel(uint32_t* hist, uint32_t n_tiles, uint32_t* bin_totals) {
+    __shared__ uint32_t s_wave[BLOCK_THREADS / WAVE];
     __shared__ uint32_t s_carry;
+    uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = lane_id(), wave = wave_id();
-    for (uint32_t base = 0; base < total_entries; base += 1024) {
+    for (uint32_t base = 0; base < n_tiles; base += BLOCK_THREADS) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < total_entries) ? hist[i] : 0u;
+        const uint32_t v = (i < n_tiles) ? row[i] : 0u;
         const uint32_t inc = wave_inclusive_scan(v);
         if (lane == WAVE - 1) s_wave[wave] = inc;
         __syncthreads();
         uint32_t off = s_carry;
         for (int w = 0; w < wave; w++) off += s_wave[w];
-        if (i < total_entries) hist[i] = off + inc - v;
+        if (i < n_tiles) row[i] = off + inc - v;
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = off + inc;
+        if (threadIdx.x == BLOCK_THREADS - 1) s_carry = off + inc;
         __syncthreads();
     }
+    if (threadIdx.x == 0) bin_totals[blockIdx.x] = s_carry;
 }
 
 // Workspace + driver for sorting up to `capacity` pairs.  `bits` = number of
@@ -278,14 +294,21 @@ public:
         keys_tmp_.resize(capacity);
         vals_tmp_.resize(capacity);
         hist_.resize((size_t)RS_BINS * tiles_);
+        bin_totals_.resize(RS_BINS);
     }
-    // sorts (keys, vals) in place (ping-pong through internal buffers); n_upper bounds the grid
-    void sort(uint32_t* keys, uint32_t* vals, const uint32_t* n_dev, size_t n_upper, int bits, hipStream_t s) {
+    struct Sorted {
+        uint32_t* keys;
+        uint32_t* vals;
+    };
+    // sorts the pairs (ping-pong between the caller's arrays and internal buffers) and
+    // returns where the sorted pairs live; n_upper bounds the grid, the exact count is
+    // read from device memory
+    Sorted sort(uint32_t* keys, uint32_t* vals, const uint32_t* n_dev, size_t n_upper, int bits, hipStream_t s) {
         reserve(n_upper);
         const uint32_t tiles = (uint32_t)((n_upper + RS_TILE - 1) / RS_TILE);
-        if (tiles == 0) return;
         uint32_t* kin = keys;
         uint32_t* vin = vals;
+        if (tiles == 0) return {kin, vin};
         uint32_t* kout = keys_tmp_.data();
         uint32_t* vout = vals_tmp_.data();
         int passes = (bits + 7) / 8;
@@ -293,22 +316,19 @@ public:
         for (int p = 0; p < passes; p++) {
             const int shift = 8 * p;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
-            hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(1), dim3(1024), 0, s, hist_.data(), (uint32_t)(RS_BINS * tiles));
+            hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
-                               hist_.data());
+                               hist_.data(), bin_totals_.data());
             std::swap(kin, kout);
             std::swap(vin, vout);
         }
-        if (kin != keys) {  // odd number of passes: results live in the temporaries
-            WF_HIP_CHECK(hipMemcpyAsync(keys, kin, n_upper * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-            WF_HIP_CHECK(hipMemcpyAsync(vals, vin, n_upper * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        }
+        return {kin, vin};
     }
     int kernels_per_sort(int bits) const { return 3 * std::max(1, (bits + 7) / 8); }
 
 private:
     size_t cap_ = 0, tiles_ = 0;
-    DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_;
+    DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_, bin_totals_;
 };
 
 // ---------------------------------------------------------------------------
