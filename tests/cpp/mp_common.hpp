@@ -26,10 +26,10 @@ struct tuple_t {
     uint64_t id = 0;
     uint64_t ts = 0;
     int64_t value = 0;
-    tuple_t() = default;
-    tuple_t(size_t k, uint64_t i, uint64_t t, int64_t v) : key(k), id(i), ts(t), value(v) {}
-    std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    void setControlFields(size_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE tuple_t() {}
+    WF_HOST_DEVICE tuple_t(size_t k, uint64_t i, uint64_t t, int64_t v) : key(k), id(i), ts(t), value(v) {}
+    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;
@@ -41,9 +41,9 @@ struct output_t {
     uint64_t id = 0;
     uint64_t ts = 0;
     int64_t value = 0;
-    output_t() = default;
-    std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    void setControlFields(size_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE output_t() {}
+    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;

@@ -1,0 +1,38 @@
+"""GPU window operators inside full MultiPipes (C++ program built with hipcc), checked
+against the sequential oracle; mirrors the reference's src/mp_test_gpu suite."""
+import os
+import subprocess
+
+import pytest
+
+from windflow_amd import build as wfbuild
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "cpp", "bin")
+
+
+def run_gpu_cpp(args, timeout=110):
+    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_mp_windows_gpu.hip"), os.path.join(BIN, "test_mp_windows_gpu"), hip=True,
+                            extra=["-I" + os.path.join(HERE, "cpp")])
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "kf+pf", "wf+wmr"]
+
+
+@pytest.mark.parametrize("op", GPU_OPS)
+@pytest.mark.parametrize("mode", ["cb", "tb"])
+def test_gpu_window_operators(op, mode):
+    win, slide = ("14", "4") if mode == "cb" else ("1000", "300")
+    out = run_gpu_cpp(["-t", op, "-m", mode, "-r", 2, "-l", 1200, "-k", 5, "-w", win, "-s", slide])
+    assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+@pytest.mark.parametrize("op", ["kf", "wf", "kff"])
+def test_gpu_window_operators_default_mode(op):
+    out = run_gpu_cpp(["-t", op, "-m", "tbd", "-r", 2, "-l", 1000, "-k", 4, "-w", "900", "-s", "300"])
+    assert out.count("  OK") == 2 and "FAILED" not in out

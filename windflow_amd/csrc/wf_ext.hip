@@ -283,6 +283,7 @@ public:
         wcfg.delay = delay;
         wcfg.type = time_based ? TB : CB;
         wcfg.max_keys = n_keys;
+        wcfg.out_capacity = batch_len;
         GPUConfig cfg;
         cfg.gpu_id = gpu_id;
         cfg.batch_len = batch_len;

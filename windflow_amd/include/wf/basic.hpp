@@ -14,6 +14,14 @@
 #include <tuple>
 #include <type_traits>
 
+// Tuple types used by GPU operators must expose their control-field accessors to
+// device code: mark them WF_HOST_DEVICE (expands to nothing for a host compiler).
+#if defined(__HIPCC__)
+#define WF_HOST_DEVICE __host__ __device__
+#else
+#define WF_HOST_DEVICE
+#endif
+
 namespace wf {
 
 // ---- time helpers (reference: basic.hpp:55-74) ----------------------------

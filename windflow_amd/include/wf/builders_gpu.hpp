@@ -9,6 +9,8 @@
 #include "gpu/batch_ops.hpp"
 #include "gpu/filter_gpu.hpp"
 #include "gpu/map_gpu.hpp"
+#include "gpu/key_ffat_gpu.hpp"
+#include "gpu/win_seq_gpu.hpp"
 
 namespace wf {
 
@@ -130,6 +132,320 @@ public:
 
 private:
     F func_;
+};
+
+
+// ---- GPU window builders -------------------------------------------------------
+// options shared by the GPU window builders: windows + GPU configuration
+template <typename Derived>
+class GPU_Window_Builder_Base : public GPU_Builder_Base<Derived> {
+public:
+    Derived& withCBWindows(uint64_t win_len, uint64_t slide_len) {
+        win_ = win_len;
+        slide_ = slide_len;
+        type_ = CB;
+        delay_ = 0;
+        return this->self();
+    }
+    Derived& withTBWindows(std::chrono::microseconds win_len, std::chrono::microseconds slide_len,
+                           std::chrono::microseconds triggering_delay = std::chrono::microseconds::zero()) {
+        win_ = (uint64_t)win_len.count();
+        slide_ = (uint64_t)slide_len.count();
+        delay_ = (uint64_t)triggering_delay.count();
+        type_ = TB;
+        return this->self();
+    }
+
+protected:
+    explicit GPU_Window_Builder_Base(std::string n) : GPU_Builder_Base<Derived>(std::move(n)) { this->cfg_.batch_len = 1; }
+    uint64_t win_ = 1, slide_ = 1, delay_ = 0;
+    win_type_t type_ = CB;
+};
+
+template <typename F>
+class WinSeqGPU_Builder : public GPU_Window_Builder_Base<WinSeqGPU_Builder<F>> {
+public:
+    using tuple_t = typename meta::win_gpu_sig<F>::tuple_t;
+    using result_t = typename meta::win_gpu_sig<F>::result_t;
+    using winseq_t = Win_Seq_GPU<tuple_t, result_t>;
+    explicit WinSeqGPU_Builder(F func) : GPU_Window_Builder_Base<WinSeqGPU_Builder<F>>("win_seq_gpu"), func_(std::move(func)) {}
+    winseq_t* build_ptr() { return new winseq_t(func_, this->win_, this->slide_, this->delay_, this->type_, this->name_, this->cfg_, this->closing_); }
+    winseq_t build() { return *std::unique_ptr<winseq_t>(build_ptr()); }
+    std::unique_ptr<winseq_t> build_unique() { return std::unique_ptr<winseq_t>(build_ptr()); }
+
+private:
+    F func_;
+};
+
+namespace detail {
+template <typename T, bool IsOp>
+struct gpu_farm_input_types {
+    using tuple_t = typename meta::win_gpu_sig<T>::tuple_t;
+    using result_t = typename meta::win_gpu_sig<T>::result_t;
+};
+template <typename A, typename B>
+struct gpu_farm_input_types<Pane_Farm_GPU<A, B>, true> {
+    using tuple_t = A;
+    using result_t = B;
+};
+template <typename A, typename B>
+struct gpu_farm_input_types<Win_MapReduce_GPU<A, B>, true> {
+    using tuple_t = A;
+    using result_t = B;
+};
+}  // namespace detail
+
+template <typename T>
+class KeyFarmGPU_Builder : public GPU_Window_Builder_Base<KeyFarmGPU_Builder<T>> {
+public:
+    static constexpr bool nested = std::is_base_of_v<Basic_Operator, T>;
+    using tuple_t = typename detail::gpu_farm_input_types<T, nested>::tuple_t;
+    using result_t = typename detail::gpu_farm_input_types<T, nested>::result_t;
+    using keyfarm_t = Key_Farm_GPU<tuple_t, result_t>;
+    template <typename U>
+    explicit KeyFarmGPU_Builder(U&& input) : GPU_Window_Builder_Base<KeyFarmGPU_Builder<T>>("key_farm_gpu"), input_(store(std::forward<U>(input))) {
+        if constexpr (nested) {
+            this->win_ = input.getWinLen();
+            this->slide_ = input.getSlideLen();
+            this->delay_ = input.getTriggeringDelay();
+            this->type_ = input.getWinType();
+        }
+    }
+    KeyFarmGPU_Builder& set_KeyBy(routing_func_t r) {
+        routing_ = std::move(r);
+        return *this;
+    }
+    KeyFarmGPU_Builder& withOptLevel(opt_level_t o) {
+        opt_ = o;
+        return *this;
+    }
+    keyfarm_t* build_ptr() {
+        if constexpr (nested)
+            return new keyfarm_t(*input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->closing_, routing_, opt_);
+        else
+            return new keyfarm_t(input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->cfg_,
+                                 this->closing_, routing_);
+    }
+    keyfarm_t build() { return *std::unique_ptr<keyfarm_t>(build_ptr()); }
+    std::unique_ptr<keyfarm_t> build_unique() { return std::unique_ptr<keyfarm_t>(build_ptr()); }
+
+private:
+    using stored_t = std::conditional_t<nested, T*, T>;
+    template <typename U>
+    static stored_t store(U&& u) {
+        if constexpr (nested)
+            return &u;
+        else
+            return stored_t(std::forward<U>(u));
+    }
+    stored_t input_;
+    routing_func_t routing_ = default_routing;
+    opt_level_t opt_ = LEVEL2;
+};
+template <typename U>
+KeyFarmGPU_Builder(U&&) -> KeyFarmGPU_Builder<std::decay_t<U>>;
+
+template <typename T>
+class WinFarmGPU_Builder : public GPU_Window_Builder_Base<WinFarmGPU_Builder<T>> {
+public:
+    static constexpr bool nested = std::is_base_of_v<Basic_Operator, T>;
+    using tuple_t = typename detail::gpu_farm_input_types<T, nested>::tuple_t;
+    using result_t = typename detail::gpu_farm_input_types<T, nested>::result_t;
+    using winfarm_t = Win_Farm_GPU<tuple_t, result_t>;
+    template <typename U>
+    explicit WinFarmGPU_Builder(U&& input) : GPU_Window_Builder_Base<WinFarmGPU_Builder<T>>("win_farm_gpu"), input_(store(std::forward<U>(input))) {
+        if constexpr (nested) {
+            this->win_ = input.getWinLen();
+            this->slide_ = input.getSlideLen();
+            this->delay_ = input.getTriggeringDelay();
+            this->type_ = input.getWinType();
+        }
+    }
+    WinFarmGPU_Builder& withOrdering(bool o) {
+        ordered_ = o;
+        return *this;
+    }
+    WinFarmGPU_Builder& withOptLevel(opt_level_t o) {
+        opt_ = o;
+        return *this;
+    }
+    winfarm_t* build_ptr() {
+        if constexpr (nested)
+            return new winfarm_t(*input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->closing_, ordered_, opt_);
+        else
+            return new winfarm_t(input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->cfg_,
+                                 this->closing_, ordered_);
+    }
+    winfarm_t build() { return *std::unique_ptr<winfarm_t>(build_ptr()); }
+    std::unique_ptr<winfarm_t> build_unique() { return std::unique_ptr<winfarm_t>(build_ptr()); }
+
+private:
+    using stored_t = std::conditional_t<nested, T*, T>;
+    template <typename U>
+    static stored_t store(U&& u) {
+        if constexpr (nested)
+            return &u;
+        else
+            return stored_t(std::forward<U>(u));
+    }
+    stored_t input_;
+    bool ordered_ = true;
+    opt_level_t opt_ = LEVEL2;
+};
+template <typename U>
+WinFarmGPU_Builder(U&&) -> WinFarmGPU_Builder<std::decay_t<U>>;
+
+namespace detail {
+// tuple / result types of a two-stage GPU operator from whichever stage is a host function
+template <typename F, typename G, bool FirstIsGPU>
+struct two_stage_gpu_types {
+    using tuple_t = typename meta::win_gpu_sig<F>::tuple_t;
+    using result_t = typename meta::win_gpu_sig<F>::result_t;
+};
+template <typename F, typename G>
+struct two_stage_gpu_types<F, G, false> {
+    using tuple_t = typename meta::win_sig<F>::tuple_t;
+    using result_t = typename meta::win_sig<F>::result_t;
+};
+}  // namespace detail
+
+template <typename Derived>
+class GPU_TwoStage_Builder_Base : public GPU_Window_Builder_Base<Derived> {
+public:
+    Derived& withParallelism(size_t first, size_t second) {
+        par1_ = first;
+        par2_ = second;
+        return this->self();
+    }
+    Derived& withOrdering(bool ordered) {
+        ordered_ = ordered;
+        return this->self();
+    }
+    Derived& withOptLevel(opt_level_t o) {
+        opt_ = o;
+        return this->self();
+    }
+    Derived& prepare4Nesting() {
+        opt_ = LEVEL2;
+        nesting_ = true;
+        return this->self();
+    }
+
+protected:
+    using GPU_Window_Builder_Base<Derived>::GPU_Window_Builder_Base;
+    size_t par1_ = 1, par2_ = 1;
+    bool ordered_ = true;
+    opt_level_t opt_ = LEVEL0;
+    bool nesting_ = false;
+};
+
+template <typename F, typename G>
+class PaneFarmGPU_Builder : public GPU_TwoStage_Builder_Base<PaneFarmGPU_Builder<F, G>> {
+public:
+    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_win_func<F>()>;
+    using tuple_t = typename types::tuple_t;
+    using result_t = typename types::result_t;
+    using panefarm_t = Pane_Farm_GPU<tuple_t, result_t>;
+    PaneFarmGPU_Builder(F plq, G wlq) : GPU_TwoStage_Builder_Base<PaneFarmGPU_Builder<F, G>>("pane_farm_gpu"), plq_(std::move(plq)), wlq_(std::move(wlq)) {}
+    panefarm_t* build_ptr() {
+        auto* p = new panefarm_t(plq_, wlq_, this->win_, this->slide_, this->delay_, this->type_, this->par1_, this->par2_, this->name_, this->cfg_,
+                                 this->closing_, this->ordered_, this->opt_);
+        if (this->nesting_) p->setPrepared4Nesting();
+        return p;
+    }
+    panefarm_t build() { return *std::unique_ptr<panefarm_t>(build_ptr()); }
+    std::unique_ptr<panefarm_t> build_unique() { return std::unique_ptr<panefarm_t>(build_ptr()); }
+
+private:
+    F plq_;
+    G wlq_;
+};
+
+template <typename F, typename G>
+class WinMapReduceGPU_Builder : public GPU_TwoStage_Builder_Base<WinMapReduceGPU_Builder<F, G>> {
+public:
+    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_win_func<F>()>;
+    using tuple_t = typename types::tuple_t;
+    using result_t = typename types::result_t;
+    using wmr_t = Win_MapReduce_GPU<tuple_t, result_t>;
+    WinMapReduceGPU_Builder(F map, G reduce) : GPU_TwoStage_Builder_Base<WinMapReduceGPU_Builder<F, G>>("win_mapreduce_gpu"), map_(std::move(map)), reduce_(std::move(reduce)) {
+        this->par1_ = 2;
+    }
+    wmr_t* build_ptr() {
+        auto* p = new wmr_t(map_, reduce_, this->win_, this->slide_, this->delay_, this->type_, this->par1_, this->par2_, this->name_, this->cfg_,
+                            this->closing_, this->ordered_, this->opt_);
+        if (this->nesting_) p->setPrepared4Nesting();
+        return p;
+    }
+    wmr_t build() { return *std::unique_ptr<wmr_t>(build_ptr()); }
+    std::unique_ptr<wmr_t> build_unique() { return std::unique_ptr<wmr_t>(build_ptr()); }
+
+private:
+    F map_;
+    G reduce_;
+};
+
+// Key_FFAT_GPU / Win_SeqFFAT_GPU: lift and combine, both device-callable
+template <typename L, typename C>
+class KeyFFATGPU_Builder : public GPU_Window_Builder_Base<KeyFFATGPU_Builder<L, C>> {
+public:
+    using tuple_t = typename meta::lift_sig<L>::tuple_t;
+    using result_t = typename meta::lift_sig<L>::result_t;
+    using keyffat_t = Key_FFAT_GPU<tuple_t, result_t>;
+    KeyFFATGPU_Builder(L lift, C comb) : GPU_Window_Builder_Base<KeyFFATGPU_Builder<L, C>>("key_ffat_gpu"), lift_(std::move(lift)), comb_(std::move(comb)) {
+        this->cfg_.batch_len = 65536;
+    }
+    // distinct keys per replica the device-resident state is sized for
+    KeyFFATGPU_Builder& withMaxKeys(size_t n) {
+        max_keys_ = n;
+        return *this;
+    }
+    // results per output batch (default: twice the input batch length)
+    KeyFFATGPU_Builder& withOutputCapacity(size_t n) {
+        out_capacity_ = n;
+        return *this;
+    }
+    KeyFFATGPU_Builder& skipEmptyGaps(bool b = true) {
+        skip_gaps_ = b;
+        return *this;
+    }
+    // kept for API parity (reference builders_gpu.hpp:955): the tree of a key is always updated incrementally
+    KeyFFATGPU_Builder& withRebuild(bool) { return *this; }
+    KeyFFATGPU_Builder& set_KeyBy(routing_func_t r) {
+        routing_ = std::move(r);
+        return *this;
+    }
+    keyffat_t* build_ptr() {
+        KeyFFATGPUConfig w;
+        w.win_len = this->win_;
+        w.slide_len = this->slide_;
+        w.delay = this->delay_;
+        w.type = this->type_;
+        w.max_keys = max_keys_;
+        w.out_capacity = out_capacity_;
+        w.skip_empty_gaps = skip_gaps_;
+        return new keyffat_t(lift_, comb_, w, this->parallelism_, this->name_, this->cfg_, this->closing_, routing_);
+    }
+    keyffat_t build() { return *std::unique_ptr<keyffat_t>(build_ptr()); }
+    std::unique_ptr<keyffat_t> build_unique() { return std::unique_ptr<keyffat_t>(build_ptr()); }
+
+private:
+    L lift_;
+    C comb_;
+    size_t max_keys_ = 1 << 16;
+    size_t out_capacity_ = 0;
+    bool skip_gaps_ = false;
+    routing_func_t routing_ = default_routing;
+};
+
+// sequential flavour: one replica (reference WinSeqFFATGPU_Builder, builders_gpu.hpp:195)
+template <typename L, typename C>
+class WinSeqFFATGPU_Builder : public KeyFFATGPU_Builder<L, C> {
+public:
+    WinSeqFFATGPU_Builder(L lift, C comb) : KeyFFATGPU_Builder<L, C>(std::move(lift), std::move(comb)) {
+        this->name_ = "win_seqffat_gpu";
+        this->parallelism_ = 1;
+    }
 };
 
 }  // namespace wf

@@ -41,6 +41,7 @@ struct FFATGeometry {
     uint32_t tree_cap;    // leaves per tree (power of two > win_panes)
     uint32_t acc_cap;     // TB: open quanta ring (power of two)
     uint32_t out_cap;     // capacity of the output batch
+    uint32_t skip_gaps;   // TB: fast-forward over long stretches of empty windows instead of emitting them
 };
 
 template <typename R>
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     // (and the windows containing them), then fast-forward over the stretch in
                     // which every window is empty instead of materialising each of them.
                     const uint64_t keep = (uint64_t)g.tree_cap + g.acc_cap;
-                    if (done_upto - st.last_quantum > 4 * keep) {
+                    if (g.skip_gaps && done_upto - st.last_quantum > 4 * keep) {
                         complete_until(st.last_quantum + keep);
                         const uint64_t skip = done_upto - keep - st.last_quantum;
                         const uint64_t panes_after = st.panes + skip;
@@ -271,8 +272,9 @@ template <typename T, typename R, typename L, typename C>
 class KeyedFFATEngine {
 public:
     KeyedFFATEngine(L lift, C comb, uint64_t win, uint64_t slide, uint64_t delay, win_type_t type, size_t max_keys, size_t batch_capacity,
-                    size_t out_capacity, int device, size_t pool_slabs)
+                    size_t out_capacity, int device, size_t pool_slabs, bool skip_gaps = false)
         : lift_(lift), comb_(comb), device_(device) {
+        g_.skip_gaps = skip_gaps ? 1u : 0u;
         if (win == 0 || slide == 0) failwith("Key_FFAT_GPU: window length or slide cannot be zero");
         if (slide >= win) failwith("Key_FFAT_GPU can be used with sliding windows only (s<w)");
         const uint64_t pane = std::gcd(win, slide);
@@ -396,7 +398,11 @@ struct KeyFFATGPUConfig {
     uint64_t win_len = 2, slide_len = 1, delay = 0;
     win_type_t type = CB;
     size_t max_keys = 1 << 16;   // distinct keys per replica the device table is sized for
-    size_t out_capacity = 0;     // results per output batch (0: same as the input batch capacity)
+    size_t out_capacity = 0;     // results per output batch (0: twice the input batch capacity)
+    // time-based windows: a key silent for much longer than a window normally produces one
+    // empty result per slide when it speaks again; true = count those windows instead of
+    // emitting them (FFATCounters::skipped_windows)
+    bool skip_empty_gaps = false;
 };
 
 template <typename tuple_t, typename result_t, typename L, typename C>
@@ -410,10 +416,10 @@ public:
 protected:
     void process_device(gpu::Batch* d) override {
         if (!engine_) {
-            const size_t out_cap = wcfg_.out_capacity ? wcfg_.out_capacity : d->capacity;
+            const size_t out_cap = wcfg_.out_capacity ? wcfg_.out_capacity : 2 * d->capacity;
             engine_.reset(new gpu::KeyedFFATEngine<tuple_t, result_t, L, C>(lift_, comb_, wcfg_.win_len, wcfg_.slide_len, wcfg_.delay, wcfg_.type,
                                                                             wcfg_.max_keys, d->capacity, out_cap, this->cfg_.gpu_id,
-                                                                            this->cfg_.pool_slabs));
+                                                                            this->cfg_.pool_slabs, wcfg_.skip_empty_gaps));
         }
         gpu::Batch* out = engine_->process(d, this->stream(), this->num_kernels_);
         d->release(this->stream());
@@ -424,7 +430,14 @@ protected:
         size_t cursor = 0;
         gpu::Batch* out = nullptr;
         while (engine_->flush_range(cursor, this->stream(), this->num_kernels_, out)) this->emit_device(out);
-        if (counters_) (*counters_)[this->context.getReplicaIndex()] = engine_->read_counters(this->stream());
+        const gpu::FFATCounters c = engine_->read_counters(this->stream());
+        if (counters_) (*counters_)[this->context.getReplicaIndex()] = c;
+        // losing results silently is not an option: fail loudly and say which knob to turn
+        if (c.overflow > 0)
+            fatal_error("Key_FFAT_GPU: " + std::to_string(c.overflow) + " window results did not fit the output batches; raise the output capacity "
+                        "(KeyFFATGPU_Builder::withOutputCapacity)");
+        if (c.table_full > 0)
+            fatal_error("Key_FFAT_GPU: the device key table is full; raise KeyFFATGPU_Builder::withMaxKeys");
     }
 
 private:

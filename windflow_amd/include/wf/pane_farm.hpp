@@ -18,14 +18,29 @@ public:
     Pane_Farm(plq_t plq_func, wlq_t wlq_func, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
               size_t plq_parallelism, size_t wlq_parallelism, std::string name, meta::closing_func_t closing = nullptr, bool ordered = true,
               opt_level_t opt_level = LEVEL0)
+        : Pane_Farm(engines_tag{}, nullptr, nullptr, win_len, slide_len, triggering_delay, type, plq_parallelism, wlq_parallelism, std::move(name),
+                    ordered, opt_level) {
+        set_engines(cpu_win_engine<tuple_t, result_t>(plq_func, closing, this->hub_), cpu_win_engine<result_t, result_t>(wlq_func, closing, this->hub_));
+    }
+
+    // generic form: the two stages are built by arbitrary engine makers (used by Pane_Farm_GPU)
+    struct engines_tag {};
+    Pane_Farm(engines_tag, win_engine_maker_t plq_maker, win_engine_maker_t wlq_maker, uint64_t win_len, uint64_t slide_len,
+              uint64_t triggering_delay, win_type_t type, size_t plq_parallelism, size_t wlq_parallelism, std::string name, bool ordered = true,
+              opt_level_t opt_level = LEVEL0)
         : name_(std::move(name)), win_(win_len), slide_(slide_len), delay_(triggering_delay), type_(type), plq_par_(plq_parallelism),
           wlq_par_(wlq_parallelism), ordered_(ordered), opt_(opt_level) {
         if (win_ == 0 || slide_ == 0) fatal_error("window length or slide in Pane_Farm cannot be zero");
         if (plq_par_ == 0 || wlq_par_ == 0) fatal_error("Pane_Farm has parallelism (PLQ or WLQ) equal to zero");
         if (win_ <= slide_) fatal_error("Pane_Farm can be used with sliding windows only (s<w)");
-        auto hub = this->hub_;
+        if (plq_maker && wlq_maker) set_engines(std::move(plq_maker), std::move(wlq_maker));
+    }
+
+protected:
+    void set_engines(win_engine_maker_t plq_maker, win_engine_maker_t wlq_maker) {
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t P = plq_par_, W = wlq_par_;
+        const win_type_t type = type_;
         group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix) {
             TwoStageGroup grp;
             const uint64_t my_slide = slide * ctx.slide_mult;
@@ -40,7 +55,7 @@ public:
                 p.winType = type;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, i, P, pane);
                 p.role = PLQ;
-                rt::Node* n = make_win_seq<tuple_t, result_t>(g, plq_func, p, prefix + "_plq", P, i, closing, hub);
+                rt::Node* n = plq_maker(g, p, prefix + "_plq", P, i);
                 grp.first_entries.push_back(n);
                 grp.first_outputs.push_back(n);
             }
@@ -61,7 +76,7 @@ public:
                 p.winType = CB;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, k, W, slide_w);
                 p.role = WLQ;
-                grp.second.push_back(make_win_seq<result_t, result_t>(g, wlq_func, p, prefix + "_wlq", W, k, closing, hub));
+                grp.second.push_back(wlq_maker(g, p, prefix + "_wlq", W, k));
             }
             grp.second_emitter = [=](rt::Graph& gr, size_t off) {
                 if (W == 1) return single_emitter(gr, new Standard_Emitter<result_t>(1), 1, off);
@@ -71,6 +86,7 @@ public:
         };
     }
 
+public:
     // ---- Basic_Operator -------------------------------------------------------
     std::string getName() const override { return name_; }
     size_t getParallelism() const override { return plq_par_ + wlq_par_; }

@@ -122,6 +122,18 @@ inline std::vector<StageSpec> assemble_two_stage(rt::Graph& g, std::vector<TwoSt
     return out;
 }
 
+// A window engine maker builds one replica of a window stage for given parameters.
+// Operators are written against makers so that the same composition logic serves
+// the CPU engines (Win_Seq_Node) and the GPU ones (Win_Seq_GPU_Node).
+using win_engine_maker_t = std::function<rt::Node*(rt::Graph&, const WinParams&, const std::string& name, size_t par, size_t idx)>;
+
+template <typename in_t, typename out_t, typename F>
+inline win_engine_maker_t cpu_win_engine(F func, meta::closing_func_t closing, std::shared_ptr<StatsHub> hub) {
+    return [func, closing, hub](rt::Graph& g, const WinParams& p, const std::string& name, size_t par, size_t idx) -> rt::Node* {
+        return g.adopt(new Win_Seq_Node<in_t, out_t, F>(func, p, name, par, idx, closing, hub));
+    };
+}
+
 // helper: window-engine replicas (role SEQ/PLQ/WLQ/MAP/REDUCE) for one farm stage
 template <typename in_t, typename out_t, typename F>
 inline rt::Node* make_win_seq(rt::Graph& g, F func, const WinParams& p, const std::string& name, size_t par, size_t idx,

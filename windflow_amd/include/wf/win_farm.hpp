@@ -19,10 +19,22 @@ public:
     template <typename F, typename = std::enable_if_t<!std::is_base_of_v<Basic_Operator, F>>>
     Win_Farm(F func, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type, size_t parallelism, std::string name,
              meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL0)
+        : Win_Farm(engines_tag{}, nullptr, win_len, slide_len, triggering_delay, type, parallelism, std::move(name), ordered, opt_level) {
+        set_engine(cpu_win_engine<tuple_t, result_t>(func, closing, hub_));
+    }
+    // generic form: replicas built by an arbitrary engine maker (used by Win_Farm_GPU)
+    struct engines_tag {};
+    Win_Farm(engines_tag, win_engine_maker_t maker, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
+             size_t parallelism, std::string name, bool ordered = true, opt_level_t opt_level = LEVEL0)
         : name_(std::move(name)), win_(win_len), slide_(slide_len), delay_(triggering_delay), type_(type), par_(parallelism),
           ordered_(ordered), opt_(opt_level) {
         check_params();
-        auto hub = hub_;
+        if (maker) set_engine(std::move(maker));
+    }
+
+protected:
+    void set_engine(win_engine_maker_t maker) {
+        const win_type_t type = type_;
         const std::string n = name_;
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t N = par_;
@@ -36,11 +48,13 @@ public:
                 p.winType = type;
                 p.config = WinOperatorConfig(0, 1, slide, i, N, slide);
                 p.role = SEQ;
-                reps.push_back(make_win_seq<tuple_t, result_t>(g, func, p, n, N, i, closing, hub));
+                reps.push_back(maker(g, p, n, N, i));
             }
             return reps;
         };
     }
+
+public:
     // ctor II / III: replicate a Pane_Farm or a Win_MapReduce `num_replicas` times
     Win_Farm(TwoStage_Operator<tuple_t, result_t>& inner, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
              size_t num_replicas, std::string name, meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL2)

@@ -19,14 +19,30 @@ public:
     Win_MapReduce(map_t map_func, reduce_t reduce_func, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
                   size_t map_parallelism, size_t reduce_parallelism, std::string name, meta::closing_func_t closing = nullptr,
                   bool ordered = true, opt_level_t opt_level = LEVEL0)
+        : Win_MapReduce(engines_tag{}, nullptr, nullptr, win_len, slide_len, triggering_delay, type, map_parallelism, reduce_parallelism,
+                        std::move(name), ordered, opt_level) {
+        set_engines(cpu_win_engine<tuple_t, result_t>(map_func, closing, this->hub_),
+                    cpu_win_engine<result_t, result_t>(reduce_func, closing, this->hub_));
+    }
+
+    // generic form: the two stages are built by arbitrary engine makers (used by Win_MapReduce_GPU)
+    struct engines_tag {};
+    Win_MapReduce(engines_tag, win_engine_maker_t map_maker, win_engine_maker_t reduce_maker, uint64_t win_len, uint64_t slide_len,
+                  uint64_t triggering_delay, win_type_t type, size_t map_parallelism, size_t reduce_parallelism, std::string name,
+                  bool ordered = true, opt_level_t opt_level = LEVEL0)
         : name_(std::move(name)), win_(win_len), slide_(slide_len), delay_(triggering_delay), type_(type), map_par_(map_parallelism),
           reduce_par_(reduce_parallelism), ordered_(ordered), opt_(opt_level) {
         if (win_ == 0 || slide_ == 0) fatal_error("window length or slide in Win_MapReduce cannot be zero");
         if (map_par_ < 2) fatal_error("Win_MapReduce must have a parallel MAP stage");
         if (reduce_par_ == 0) fatal_error("parallelism of the REDUCE stage cannot be zero");
-        auto hub = this->hub_;
+        if (map_maker && reduce_maker) set_engines(std::move(map_maker), std::move(reduce_maker));
+    }
+
+protected:
+    void set_engines(win_engine_maker_t map_maker, win_engine_maker_t reduce_maker) {
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t M = map_par_, R = reduce_par_;
+        const win_type_t type = type_;
         group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix) {
             TwoStageGroup grp;
             const uint64_t my_slide = slide * ctx.slide_mult;
@@ -41,7 +57,7 @@ public:
                 p.role = MAP;
                 p.map_first = i;
                 p.map_stride = M;
-                rt::Node* seq = make_win_seq<tuple_t, result_t>(g, map_func, p, prefix + "_map", M, i, closing, hub);
+                rt::Node* seq = map_maker(g, p, prefix + "_map", M, i);
                 if (type == CB) {
                     rt::Node* drop = g.adopt(new WinMap_Dropper<tuple_t>(i, M));
                     g.connect_fused(drop, drop->add_out_port(), seq);
@@ -62,7 +78,7 @@ public:
                 p.winType = CB;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, k, R, M);
                 p.role = REDUCE;
-                grp.second.push_back(make_win_seq<result_t, result_t>(g, reduce_func, p, prefix + "_reduce", R, k, closing, hub));
+                grp.second.push_back(reduce_maker(g, p, prefix + "_reduce", R, k));
             }
             grp.second_emitter = [=](rt::Graph& gr, size_t off) {
                 if (R == 1) return single_emitter(gr, new Standard_Emitter<result_t>(1), 1, off);
@@ -72,6 +88,7 @@ public:
         };
     }
 
+public:
     std::string getName() const override { return name_; }
     size_t getParallelism() const override { return map_par_ + reduce_par_; }
     routing_modes_t getRoutingMode() const override { return COMPLEX; }

@@ -10,4 +10,5 @@
 #include "gpu/primitives.hpp"
 #include "gpu/flatfat_gpu.hpp"
 #include "gpu/key_ffat_gpu.hpp"
+#include "gpu/win_seq_gpu.hpp"
 #include "builders_gpu.hpp"
