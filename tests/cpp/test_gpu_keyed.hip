@@ -1,0 +1,191 @@
+// Keyed (stateful) GPU operators and the device KeyBy emitter inside MultiPipes.
+//   A: Source (tuples) -> keyed Map_GPU (per-key running sum) -> Sink
+//   B: Batch_Source -> [KeyBy_EmitterGPU] keyed Map_GPU -> [KeyBy_EmitterGPU] keyed Filter_GPU -> Sink
+//   C: Batch_Source -> [KeyBy_EmitterGPU] Key_FFAT_GPU -> Sink
+// every run draws random parallelism / batch sizes and is checked against host oracles.
+#include <iostream>
+#include <map>
+#include <random>
+
+#include <wf/windflow_gpu.hpp>
+
+#include "mp_common.hpp"
+
+using namespace wf;
+using namespace std;
+
+// per-key running sum kept in the scratchpad
+struct RunningSum {
+    __host__ __device__ void operator()(tuple_t& t, char* state, size_t) const {
+        int64_t* acc = reinterpret_cast<int64_t*>(state);
+        *acc += t.value;
+        t.value = *acc;
+    }
+};
+// out-of-place flavour
+struct RunningSumOut {
+    __host__ __device__ void operator()(const tuple_t& t, output_t& r, char* state, size_t) const {
+        int64_t* acc = reinterpret_cast<int64_t*>(state);
+        *acc += t.value;
+        r.setControlFields(t.key, t.id, t.ts);
+        r.value = *acc;
+    }
+};
+// keeps the 1st, 4th, 7th ... tuple of every key
+struct EveryThird {
+    __host__ __device__ void operator()(const tuple_t& t, bool& keep, char* state, size_t) const {
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(state);
+        keep = (*cnt % 3) == 0;
+        (*cnt)++;
+        (void)t;
+    }
+};
+struct Lift_GPU {
+    __host__ __device__ void operator()(const tuple_t& t, output_t& r) const { r.value = t.value; }
+};
+struct Comb_GPU {
+    __host__ __device__ void operator()(const output_t& a, const output_t& b, output_t& out) const { out.value = a.value + b.value; }
+};
+
+// deterministic stream: n tuples, keys drawn by an LCG, value = small ints
+struct Gen {
+    size_t n, keys, sent = 0;
+    uint64_t state = 99;
+    Gen(size_t n_, size_t k_) : n(n_), keys(k_) {}
+    bool operator()(tuple_t& t) {
+        state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+        t.key = (state >> 33) % keys;
+        t.id = sent;
+        t.ts = sent;
+        t.value = (int64_t)((state >> 20) % 17) - 8;
+        sent++;
+        return sent < n;
+    }
+};
+
+static vector<tuple_t> materialize(size_t n, size_t keys) {
+    Gen g(n, keys);
+    vector<tuple_t> v;
+    bool more = true;
+    while (more) {
+        tuple_t t;
+        more = g(t);
+        v.push_back(t);
+    }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 60000;
+    const size_t keys = argc > 2 ? (size_t)atol(argv[2]) : 37;
+    const size_t runs = argc > 3 ? (size_t)atol(argv[3]) : 2;
+    if (gpu::device_count() < 1) return 3;
+    const auto stream = materialize(n, keys);
+    // oracles
+    long exp_a = 0, exp_b_sum = 0, exp_b_cnt = 0;
+    {
+        map<size_t, int64_t> acc;
+        map<size_t, uint32_t> cnt;
+        for (auto& t : stream) {
+            acc[t.key] += t.value;
+            exp_a += acc[t.key];
+            if (cnt[t.key]++ % 3 == 0) {
+                exp_b_sum += acc[t.key];
+                exp_b_cnt++;
+            }
+        }
+    }
+    const uint64_t win = 12, slide = 4;
+    long exp_c_sum = 0, exp_c_cnt = 0;
+    {
+        map<size_t, vector<int64_t>> per;
+        for (auto& t : stream) per[t.key].push_back(t.value);
+        for (auto& kv : per) {
+            const auto& v = kv.second;
+            for (size_t w = 0; w * slide < v.size(); w++) {
+                for (size_t i = w * slide; i < min(v.size(), w * slide + win); i++) exp_c_sum += v[i];
+                exp_c_cnt++;
+            }
+        }
+    }
+    std::mt19937 rng(std::random_device{}());
+    std::uniform_int_distribution<int> dp(1, 4), db(1, 40);
+    int failures = 0;
+    for (size_t run = 0; run < runs; run++) {
+        const size_t p1 = (size_t)dp(rng), p2 = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        // ---- A ----------------------------------------------------------------
+        {
+            SinkTotals tot;
+            PipeGraph g("keyed_a", Mode::DEFAULT);
+            Source src = Source_Builder(Gen(n, keys)).withParallelism(1).build();
+            MultiPipe& mp = g.add_source(src);
+            auto map = MapGPU_Builder(RunningSum()).withName("kmap").withParallelism(p1).withBatch(batch).withScratchpad(16).withMaxKeys(keys)
+                           .build_unique();
+            mp.add(*map);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                            if (o) {
+                                sum += o->value;
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_a && cnt == (long)n);
+            cout << "A par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        // ---- B ----------------------------------------------------------------
+        {
+            PipeGraph g("keyed_b", Mode::DEFAULT);
+            auto src = BatchSource_Builder(Gen(n, keys)).withParallelism(1).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto map = MapGPU_Builder(RunningSumOut()).withName("kmap").withParallelism(p1).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*map);
+            auto fil = FilterGPU_Builder([] __host__ __device__(const output_t&, bool& keep, char* st, size_t) {
+                           uint32_t* c = reinterpret_cast<uint32_t*>(st);
+                           keep = (*c % 3) == 0;
+                           (*c)++;
+                       }).withName("kfilter").withParallelism(p2).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*fil);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
+                            if (o) {
+                                sum += o->value;
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_b_sum && cnt == exp_b_cnt);
+            cout << "B par=" << p1 << "," << p2 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << exp_b_sum << " "
+                 << exp_b_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        // ---- C ----------------------------------------------------------------
+        {
+            PipeGraph g("keyed_c", Mode::DEFAULT);
+            auto src = BatchSource_Builder(Gen(n, keys)).withParallelism(1).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto kff = KeyFFATGPU_Builder(Lift_GPU(), Comb_GPU()).withName("kff").withCBWindows(win, slide).withParallelism(p1).withMaxKeys(keys)
+                           .withOutputCapacity(1 << 16).build_unique();
+            mp.add(*kff);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
+                            if (o) {
+                                sum += o->value;
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_c_sum && cnt == exp_c_cnt);
+            cout << "C par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << exp_c_sum << " " << exp_c_cnt
+                 << ")" << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+    }
+    (void)EveryThird{};
+    return failures == 0 ? 0 : 1;
+}

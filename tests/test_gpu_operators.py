@@ -36,3 +36,18 @@ def test_gpu_window_operators(op, mode):
 def test_gpu_window_operators_default_mode(op):
     out = run_gpu_cpp(["-t", op, "-m", "tbd", "-r", 2, "-l", 1000, "-k", 4, "-w", "900", "-s", "300"])
     assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+def run_keyed_cpp(args, timeout=110):
+    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_gpu_keyed.hip"), os.path.join(BIN, "test_gpu_keyed"), hip=True,
+                            extra=["-I" + os.path.join(HERE, "cpp")])
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("n,keys", [(60000, 37), (20000, 1), (50000, 3000)])
+def test_keyed_gpu_operators_and_device_keyby(n, keys):
+    """Keyed Map_GPU / Filter_GPU (per-key scratchpad state) and Key_FFAT_GPU behind the device KeyBy emitter."""
+    out = run_keyed_cpp([n, keys, 2])
+    assert out.count("  OK") == 6 and "FAILED" not in out

@@ -284,6 +284,7 @@ public:
         wcfg.type = time_based ? TB : CB;
         wcfg.max_keys = n_keys;
         wcfg.out_capacity = batch_len;
+        wcfg.lanes_are_key_disjoint = true;  // the generator gives every source its own keys
         GPUConfig cfg;
         cfg.gpu_id = gpu_id;
         cfg.batch_len = batch_len;

@@ -10,6 +10,8 @@
 #include "gpu/filter_gpu.hpp"
 #include "gpu/map_gpu.hpp"
 #include "gpu/key_ffat_gpu.hpp"
+#include "gpu/keyed_gpu.hpp"
+#include "gpu/keyby_gpu.hpp"
 #include "gpu/win_seq_gpu.hpp"
 
 namespace wf {
@@ -49,16 +51,24 @@ protected:
     GPUConfig cfg_;
 };
 
+// Map_GPU: the functor signature selects the variant (reference: wf/map_gpu.hpp:103-117)
+//   void(T&)                                   stateless, in place
+//   void(const T&, R&)                         stateless, out of place
+//   void(T&, char*, size_t)                    keyed, in place, per-key scratchpad
+//   void(const T&, R&, char*, size_t)          keyed, out of place, per-key scratchpad
 template <typename F>
 class MapGPU_Builder : public GPU_Builder_Base<MapGPU_Builder<F>> {
 public:
-    using tuple_t = meta::arg_bare_t<F, 0>;
-    static constexpr bool in_place = meta::arity_v<F> == 1;
-    static_assert(meta::arity_v<F> == 1 || meta::arity_v<F> == 2,
+    static constexpr size_t arity = meta::arity_v<F>;
+    static_assert(arity >= 1 && arity <= 4,
                   "WindFlow Compilation Error - unknown signature passed to the MapGPU_Builder:\n"
                   "  Candidate 1 : __host__ __device__ void(tuple_t &)\n"
                   "  Candidate 2 : __host__ __device__ void(const tuple_t &, result_t &)\n"
-                  "  (keyed forms with a scratchpad: see KeyedMapGPU_Builder)");
+                  "  Candidate 3 : __host__ __device__ void(tuple_t &, char *, size_t)\n"
+                  "  Candidate 4 : __host__ __device__ void(const tuple_t &, result_t &, char *, size_t)");
+    using tuple_t = meta::arg_bare_t<F, 0>;
+    static constexpr bool keyed = arity >= 3;
+    static constexpr bool in_place = (arity == 1 || arity == 3);
     template <bool B, typename X>
     struct res {
         using type = tuple_t;
@@ -68,32 +78,80 @@ public:
         using type = meta::arg_bare_t<X, 1>;
     };
     using result_t = typename res<in_place, F>::type;
-    using map_t = Map_GPU<tuple_t, result_t>;
+    using map_t = std::conditional_t<keyed, Keyed_GPU_Operator<in_place ? 0 : 1, tuple_t, result_t>, Map_GPU<tuple_t, result_t>>;
     explicit MapGPU_Builder(F func) : GPU_Builder_Base<MapGPU_Builder<F>>("map_gpu"), func_(std::move(func)) {}
-    map_t build() { return map_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_); }
-    map_t* build_ptr() { return new map_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_); }
+    // keyed variants: distinct keys per replica / custom host routing / key-disjoint batch lanes
+    MapGPU_Builder& withMaxKeys(size_t n) {
+        kcfg_.max_keys = n;
+        return *this;
+    }
+    MapGPU_Builder& enable_KeyBy(routing_func_t r = default_routing) {
+        routing_ = std::move(r);
+        return *this;
+    }
+    MapGPU_Builder& withKeyDisjointLanes(bool b = true) {
+        kcfg_.lanes_are_key_disjoint = b;
+        return *this;
+    }
+    map_t* build_ptr() {
+        if constexpr (keyed) {
+            kcfg_.state_size = this->cfg_.scratchpad_size ? this->cfg_.scratchpad_size : 64;
+            return new map_t(func_, this->parallelism_, this->name_, kcfg_, this->cfg_, this->closing_, routing_);
+        } else {
+            return new map_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_);
+        }
+    }
+    map_t build() { return *std::unique_ptr<map_t>(build_ptr()); }
     std::unique_ptr<map_t> build_unique() { return std::unique_ptr<map_t>(build_ptr()); }
 
 private:
     F func_;
+    KeyedGPUConfig kcfg_;
+    routing_func_t routing_ = default_routing;
 };
 
+// Filter_GPU:  void(const T&, bool&) | bool(const T&)   stateless
+//              void(const T&, bool&, char*, size_t)      keyed, per-key scratchpad
 template <typename F>
 class FilterGPU_Builder : public GPU_Builder_Base<FilterGPU_Builder<F>> {
 public:
-    using tuple_t = meta::arg_bare_t<F, 0>;
-    static_assert(meta::arity_v<F> == 1 || meta::arity_v<F> == 2,
+    static constexpr size_t arity = meta::arity_v<F>;
+    static_assert(arity == 1 || arity == 2 || arity == 4,
                   "WindFlow Compilation Error - unknown signature passed to the FilterGPU_Builder:\n"
                   "  Candidate 1 : __host__ __device__ void(const tuple_t &, bool &)\n"
-                  "  Candidate 2 : __host__ __device__ bool(const tuple_t &)");
-    using filter_t = Filter_GPU<tuple_t>;
+                  "  Candidate 2 : __host__ __device__ bool(const tuple_t &)\n"
+                  "  Candidate 3 : __host__ __device__ void(const tuple_t &, bool &, char *, size_t)");
+    using tuple_t = meta::arg_bare_t<F, 0>;
+    static constexpr bool keyed = arity == 4;
+    using filter_t = std::conditional_t<keyed, Keyed_GPU_Operator<2, tuple_t, tuple_t>, Filter_GPU<tuple_t>>;
     explicit FilterGPU_Builder(F func) : GPU_Builder_Base<FilterGPU_Builder<F>>("filter_gpu"), func_(std::move(func)) {}
-    filter_t build() { return filter_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_); }
-    filter_t* build_ptr() { return new filter_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_); }
+    FilterGPU_Builder& withMaxKeys(size_t n) {
+        kcfg_.max_keys = n;
+        return *this;
+    }
+    FilterGPU_Builder& enable_KeyBy(routing_func_t r = default_routing) {
+        routing_ = std::move(r);
+        return *this;
+    }
+    FilterGPU_Builder& withKeyDisjointLanes(bool b = true) {
+        kcfg_.lanes_are_key_disjoint = b;
+        return *this;
+    }
+    filter_t* build_ptr() {
+        if constexpr (keyed) {
+            kcfg_.state_size = this->cfg_.scratchpad_size ? this->cfg_.scratchpad_size : 64;
+            return new filter_t(func_, this->parallelism_, this->name_, kcfg_, this->cfg_, this->closing_, routing_);
+        } else {
+            return new filter_t(func_, this->parallelism_, this->name_, this->cfg_, this->closing_);
+        }
+    }
+    filter_t build() { return *std::unique_ptr<filter_t>(build_ptr()); }
     std::unique_ptr<filter_t> build_unique() { return std::unique_ptr<filter_t>(build_ptr()); }
 
 private:
     F func_;
+    KeyedGPUConfig kcfg_;
+    routing_func_t routing_ = default_routing;
 };
 
 template <typename F>
@@ -405,6 +463,10 @@ public:
         out_capacity_ = n;
         return *this;
     }
+    KeyFFATGPU_Builder& withKeyDisjointLanes(bool b = true) {
+        disjoint_ = b;
+        return *this;
+    }
     KeyFFATGPU_Builder& skipEmptyGaps(bool b = true) {
         skip_gaps_ = b;
         return *this;
@@ -424,6 +486,7 @@ public:
         w.max_keys = max_keys_;
         w.out_capacity = out_capacity_;
         w.skip_empty_gaps = skip_gaps_;
+        w.lanes_are_key_disjoint = disjoint_;
         return new keyffat_t(lift_, comb_, w, this->parallelism_, this->name_, this->cfg_, this->closing_, routing_);
     }
     keyffat_t build() { return *std::unique_ptr<keyffat_t>(build_ptr()); }
@@ -435,6 +498,7 @@ private:
     size_t max_keys_ = 1 << 16;
     size_t out_capacity_ = 0;
     bool skip_gaps_ = false;
+    bool disjoint_ = false;
     routing_func_t routing_ = default_routing;
 };
 

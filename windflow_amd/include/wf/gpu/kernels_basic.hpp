@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         keep[k] = false;
         if (idx < n) {
             vals[k] = in[idx];
-            keep[k] = pred(vals[k]);
+            keep[k] = pred(vals[k], idx);
         }
         const unsigned long long b = __ballot(keep[k]);
         rank[k] = (uint32_t)__popcll(b & lanemask_lt());
@@ -195,6 +195,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 template <typename T, typename F>
 struct PredicateAdapter {
     F f;
+    // the compaction kernel passes the position of the tuple too (used by FlagPredicate)
+    __host__ __device__ bool operator()(const T& t, uint32_t) const { return (*this)(t); }
     __host__ __device__ bool operator()(const T& t) const {
         if constexpr (std::is_same_v<decltype(call(f, t, 0)), bool>) {
             return call(f, t, 0);
@@ -212,6 +214,14 @@ private:
     }
     template <typename G>
     __host__ __device__ static void call(const G&, const T&, long) {}
+};
+
+// keep tuple i iff flags[i] != 0 (keyed filters evaluate the predicate in a separate,
+// per-key ordered pass and compact afterwards)
+template <typename T>
+struct FlagPredicate {
+    const uint8_t* flags;
+    __host__ __device__ bool operator()(const T&, uint32_t i) const { return flags[i] != 0; }
 };
 
 }  // namespace gpu

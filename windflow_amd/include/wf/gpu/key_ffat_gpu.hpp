@@ -27,6 +27,7 @@
 
 #include "batch_ops.hpp"
 #include "flatfat_gpu.hpp"
+#include "keyby_gpu.hpp"
 #include "primitives.hpp"
 
 namespace wf {
@@ -403,6 +404,9 @@ struct KeyFFATGPUConfig {
     // empty result per slide when it speaks again; true = count those windows instead of
     // emitting them (FFATCounters::skipped_windows)
     bool skip_empty_gaps = false;
+    // batch input only: lane i already carries exactly the keys of replica i (key-partitioned
+    // source or upstream exchange); otherwise batches go through the device KeyBy emitter
+    bool lanes_are_key_disjoint = false;
 };
 
 template <typename tuple_t, typename result_t, typename L, typename C>
@@ -459,7 +463,7 @@ public:
     Key_FFAT_GPU(L lift, C comb, KeyFFATGPUConfig wcfg, size_t parallelism, std::string name, GPUConfig cfg = GPUConfig(),
                  meta::closing_func_t closing = nullptr, routing_func_t routing = default_routing)
         : name_(std::move(name)), par_(parallelism), wcfg_(wcfg), routing_(std::move(routing)), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)),
-          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)), slabs_(cfg.pool_slabs) {
+          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)), slabs_(cfg.pool_slabs), gpu_id_(cfg.gpu_id) {
         if (par_ == 0) fatal_error("Key_FFAT_GPU has parallelism zero");
         auto hub = hub_;
         auto kind = kind_;
@@ -490,8 +494,21 @@ public:
     std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
         StageSpec s;
         s.name = name_;
-        s.replicas = factory_(g);
         const size_t N = par_;
+        const edge_kind_t kind = *kind_;
+        if (kind != EDGE_TUPLE && !wcfg_.lanes_are_key_disjoint && N > 1) {
+            // device KeyBy: the emitter ships host batches itself and hands device sub-batches over
+            *kind_ = EDGE_DEVICE_BATCH;
+            s.replicas = factory_(g);
+            s.routing = COMPLEX;
+            const int dev = gpu_id_;
+            const size_t slabs = slabs_;
+            s.make_emitter = [N, kind, dev, slabs](rt::Graph& gr, size_t) {
+                return single_emitter(gr, new KeyBy_EmitterGPU<tuple_t>(N, kind, dev, slabs), N);
+            };
+            return {s};
+        }
+        s.replicas = factory_(g);
         if (*kind_ == EDGE_TUPLE) {
             s.routing = COMPLEX;
             routing_func_t rf = routing_;
@@ -517,6 +534,7 @@ private:
     std::shared_ptr<edge_kind_t> kind_;
     std::shared_ptr<std::vector<gpu::FFATCounters>> counters_;
     size_t slabs_;
+    int gpu_id_;
     std::function<std::vector<rt::Node*>(rt::Graph&)> factory_;
 };
 

@@ -1,0 +1,179 @@
+// KeyBy on the device: partition a batch by destination without leaving the GPU.
+//
+// Capability parity with the fork's Standard_EmitterGPU
+// (/root/reference/wf/standard_nodes_gpu.hpp:60-225: KEYBY of a device-resident
+// batch into per-destination device sub-batches; its "linear" variant goes
+// through the host, its "parallel" variant does one scan+scatter pass PER
+// destination and is behind an #ifdef, getOutputQueue is unimplemented) and with
+// the scattering studies (src/GPU_Tests/scattering/test_v1..v4).  Here: one
+// destination computation, one stable radix pass on log2(P) bits, one offsets
+// kernel and one scatter kernel, whatever P; the P sub-batches keep arrival order
+// and carry their counts in device headers + pinned mirrors, so neither a GPU
+// consumer nor the RCCL exchange (dist/exchange.hpp) needs the host to size them.
+#pragma once
+#include "batch_ops.hpp"
+#include "primitives.hpp"
+
+namespace wf {
+namespace gpu {
+
+constexpr int MAX_PARTITIONS = 16;
+
+template <typename T>
+struct DestTable {
+    BatchHeader* hdr[MAX_PARTITIONS];
+    T* data[MAX_PARTITIONS];
+    volatile uint32_t* mirror[MAX_PARTITIONS];
+};
+
+// offsets[d] = first sorted position whose destination is >= d; offsets[n_dest] = n
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    partition_offsets_kernel(const BatchHeader* hdr, const uint32_t* sorted_dest, uint32_t n_dest, uint32_t* offsets) {
+    const uint32_t n = hdr->count;
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x <= n_dest) offsets[threadIdx.x] = 0;
+        return;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = sorted_dest[i];
+        const uint32_t first = (i == 0) ? 0u : sorted_dest[i - 1] + 1u;
+        for (uint32_t x = first; x <= d; x++) offsets[x] = i;
+        if (i == n - 1)
+            for (uint32_t x = d + 1; x <= n_dest; x++) offsets[x] = n;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    partition_scatter_kernel(const BatchHeader* in_hdr, const T* in, const uint32_t* sorted_dest, const uint32_t* perm, const uint32_t* offsets,
+                             DestTable<T> tab, uint32_t n_dest) {
+    const uint32_t n = in_hdr->count;
+    if (blockIdx.x == 0 && threadIdx.x < n_dest) {
+        BatchHeader h = *in_hdr;
+        h.count = offsets[threadIdx.x + 1] - offsets[threadIdx.x];
+        *tab.hdr[threadIdx.x] = h;
+        *tab.mirror[threadIdx.x] = h.count;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = sorted_dest[i];
+        tab.data[d][i - offsets[d]] = in[perm[i]];
+    }
+}
+
+// Partitions device batches of T into n_dest device batches (stable within a destination).
+template <typename T>
+class BatchPartitioner {
+public:
+    BatchPartitioner(size_t n_dest, int device, size_t pool_slabs) : n_dest_(n_dest), device_(device), pool_slabs_(pool_slabs) {
+        if (n_dest_ == 0 || n_dest_ > (size_t)MAX_PARTITIONS) failwith("BatchPartitioner: unsupported number of destinations");
+        bits_ = 1;
+        while ((1u << bits_) < n_dest_) bits_++;
+    }
+    // enqueue on `s`; `outs` receives n_dest batches whose counts live on the device (+ pinned mirrors)
+    void partition(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels) {
+        const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
+        if (!pool_) {
+            pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(T), in->capacity, n_dest_ * pool_slabs_));
+            dest_.resize(in->capacity);
+            idx_.resize(in->capacity);
+            offsets_.resize(MAX_PARTITIONS + 1);
+            sorter_.reserve(in->capacity);
+        }
+        outs.clear();
+        DestTable<T> tab{};
+        for (size_t d = 0; d < n_dest_; d++) {
+            Batch* o = pool_->acquire(s);
+            o->host_hdr = in->host_hdr;
+            o->count_on_host = false;
+            tab.hdr[d] = o->header();
+            tab.data[d] = o->template data<T>();
+            tab.mirror[d] = o->count_mirror;
+            outs.push_back(o);
+        }
+        const unsigned grid = grid_for(std::max<size_t>(upper, 1));
+        hipLaunchKernelGGL((dest_keys_kernel<T, KeyOfAny>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                           (uint32_t)n_dest_, dest_.data(), idx_.data(), KeyOfAny{});
+        const auto sorted = sorter_.sort(dest_.data(), idx_.data(), in->device_count_ptr(), std::max<size_t>(upper, 1), bits_, s);
+        hipLaunchKernelGGL(partition_offsets_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), sorted.keys, (uint32_t)n_dest_,
+                           offsets_.data());
+        hipLaunchKernelGGL((partition_scatter_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                           sorted.keys, sorted.vals, offsets_.data(), tab, (uint32_t)n_dest_);
+        kernels += 3 + sorter_.kernels_per_sort(bits_);
+    }
+    size_t n_dest() const { return n_dest_; }
+
+private:
+    struct KeyOfAny {
+        __host__ __device__ uint64_t operator()(const T& t) const { return (uint64_t)std::get<0>(t.getControlFields()); }
+    };
+    size_t n_dest_;
+    int device_;
+    size_t pool_slabs_;
+    int bits_ = 1;
+    std::unique_ptr<BatchPool> pool_;
+    DeviceBuffer<uint32_t> dest_, idx_, offsets_;
+    RadixSorter sorter_;
+};
+
+// destination of a key under the device KeyBy (host code can call it too)
+__host__ __device__ inline uint32_t keyby_destination(uint64_t key, uint32_t n_dest) { return (uint32_t)(mix64(key) % n_dest); }
+
+}  // namespace gpu
+
+// Emitter node fused on a producer of batches: ships host batches to the device if
+// needed, partitions by key and sends sub-batch d to destination d.
+template <typename T>
+class KeyBy_EmitterGPU : public rt::Node {
+public:
+    KeyBy_EmitterGPU(size_t n_dest, edge_kind_t in_kind, int device, size_t pool_slabs)
+        : n_dest_(n_dest), in_kind_(in_kind), device_(device), slabs_(pool_slabs), part_(n_dest, device, pool_slabs) {
+        for (size_t i = 0; i < n_dest_; i++) add_out_port();
+    }
+    void svc_init() override {
+        WF_HIP_CHECK(hipSetDevice(device_));
+        stream_.reset(new gpu::Stream());
+    }
+    void svc(void* msg, int) override {
+        gpu::Batch* b = static_cast<gpu::Batch*>(msg);
+        gpu::Batch* d = b;
+        hipStream_t s = stream_->get();
+        if (in_kind_ == EDGE_HOST_BATCH) {
+            if (!in_pool_) in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, device_, sizeof(T), b->capacity, slabs_));
+            d = in_pool_->acquire(s);
+            *b->header() = b->host_hdr;
+            WF_HIP_CHECK(hipMemcpyAsync(d->slab, b->slab, b->bytes_used(), hipMemcpyHostToDevice, s));
+            d->host_hdr = b->host_hdr;
+            d->count_on_host = true;
+            b->release(s);
+        } else {
+            d->ready.wait_on(s);
+        }
+        if (n_dest_ == 1) {
+            d->ready.record(s);
+            emit_to(d, 0);
+            return;
+        }
+        std::vector<gpu::Batch*> outs;
+        part_.partition(d, s, outs, kernels_);
+        d->release(s);
+        for (size_t p = 0; p < n_dest_; p++) {
+            outs[p]->ready.record(s);
+            emit_to(outs[p], p);
+        }
+    }
+    void svc_end() override {
+        if (stream_) stream_->sync();
+    }
+
+private:
+    size_t n_dest_;
+    edge_kind_t in_kind_;
+    int device_;
+    size_t slabs_;
+    gpu::BatchPartitioner<T> part_;
+    std::unique_ptr<gpu::Stream> stream_;
+    std::unique_ptr<gpu::BatchPool> in_pool_;
+    uint64_t kernels_ = 0;
+};
+
+}  // namespace wf

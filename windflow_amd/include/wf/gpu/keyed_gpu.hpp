@@ -1,0 +1,263 @@
+// Keyed (stateful) Map_GPU and Filter_GPU: the user functor receives, besides the
+// tuple, a per-KEY scratchpad that persists across batches
+//     map    in place : void(tuple_t&, char* state, size_t size)
+//     map    out-of-pl: void(const tuple_t&, result_t&, char* state, size_t size)
+//     filter          : void(const tuple_t&, bool& keep, char* state, size_t size)
+// and the tuples of a key are processed in arrival order.
+//
+// Capability parity with the keyed variants of the fork's MapGPU_Node /
+// FilterGPU_Node (/root/reference/wf/map_gpu_node.hpp:89-125, :372-399, :492-496;
+// wf/filter_gpu_node.hpp:61-76) and with the stateful benchmarks
+// (src/GPU_Tests/new_tests/benchmarks/gpu_map_stateful.cpp:410-431,
+// gpu_filter_stateful.cpp).  The reference kernels make EVERY thread scan the whole
+// batch (O(N*threads), K7/K8/K10); the benchmarks instead build per-key linked
+// lists on the host while filling the batch and allocate each key's state with its
+// own cudaMalloc.  Here everything is on the device: keys map to slots through a
+// hash table, a stable radix sort of (slot, index) gives each key a contiguous
+// run in arrival order, one thread walks each run, and the states are one slab
+// indexed by slot (zero-initialised when a key first appears).
+#pragma once
+#include "batch_ops.hpp"
+#include "keyby_gpu.hpp"
+#include "kernels_basic.hpp"
+#include "primitives.hpp"
+
+namespace wf {
+namespace gpu {
+
+// mode 0: in-place map, 1: out-of-place map, 2: filter flags
+template <int MODE, typename T, typename R, typename F>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    keyed_apply_kernel(const BatchHeader* hdr, T* data, R* out, uint8_t* flags, const uint32_t* sslot, const uint32_t* sidx, char* states,
+                       size_t state_size, uint32_t* table_full, F f) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = sslot[i];
+        if (i > 0 && sslot[i - 1] == slot) continue;
+        if (slot == 0xffffffffu) {
+            atomicAdd(table_full, 1u);
+            continue;
+        }
+        char* st = states + (size_t)slot * state_size;
+        for (uint32_t j = i; j < n && sslot[j] == slot; j++) {
+            const uint32_t p = sidx[j];
+            if constexpr (MODE == 0) {
+                T t = data[p];
+                f(t, st, state_size);
+                data[p] = t;
+            } else if constexpr (MODE == 1) {
+                const T t = data[p];
+                R r{};
+                f(t, r, st, state_size);
+                out[p] = r;
+            } else {
+                const T t = data[p];
+                bool keep = false;
+                f(t, keep, st, state_size);
+                flags[p] = keep ? 1 : 0;
+            }
+        }
+    }
+}
+
+struct KeyOfTupleK {
+    template <typename T>
+    __host__ __device__ uint64_t operator()(const T& t) const {
+        return (uint64_t)std::get<0>(t.getControlFields());
+    }
+};
+
+// device-resident keyed context: key table + sorter + state slab
+class KeyedContext {
+public:
+    KeyedContext(size_t max_keys, size_t state_size, size_t batch_capacity, int device) : state_size_(state_size ? state_size : 1) {
+        WF_HIP_CHECK(hipSetDevice(device));
+        table_cap_ = 2;
+        while (table_cap_ < 2 * max_keys) table_cap_ <<= 1;
+        while ((1ull << slot_bits_) < table_cap_) slot_bits_++;
+        table_.resize(table_cap_);
+        WF_HIP_CHECK(hipMemset(table_.data(), 0xff, table_.bytes()));
+        states_.resize(table_cap_ * state_size_);
+        WF_HIP_CHECK(hipMemset(states_.data(), 0, states_.bytes()));
+        slot_.resize(batch_capacity);
+        idx_.resize(batch_capacity);
+        full_.resize(1);
+        WF_HIP_CHECK(hipMemset(full_.data(), 0, 4));
+        sorter_.reserve(batch_capacity);
+    }
+    template <typename T>
+    RadixSorter::Sorted group(Batch* in, hipStream_t s, uint64_t& kernels) {
+        const size_t upper = std::max<size_t>(1, in->count_on_host ? in->host_hdr.count : in->capacity);
+        hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTupleK>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(),
+                           in->template data<T>(), table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), full_.data(), KeyOfTupleK{});
+        kernels += 1 + sorter_.kernels_per_sort(slot_bits_ + 1);
+        return sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+    }
+    char* states() const { return states_.data(); }
+    size_t state_size() const { return state_size_; }
+    uint32_t* table_full_counter() const { return full_.data(); }
+    uint32_t read_table_full(hipStream_t s) {
+        uint32_t v = 0;
+        WF_HIP_CHECK(hipMemcpyAsync(&v, full_.data(), 4, hipMemcpyDeviceToHost, s));
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+        return v;
+    }
+
+private:
+    size_t state_size_, table_cap_ = 0;
+    int slot_bits_ = 0;
+    DeviceBuffer<unsigned long long> table_;
+    DeviceBuffer<char> states_;
+    DeviceBuffer<uint32_t> slot_, idx_, full_;
+    RadixSorter sorter_;
+};
+
+}  // namespace gpu
+
+struct KeyedGPUConfig {
+    size_t max_keys = 1 << 16;     // distinct keys per replica
+    size_t state_size = 64;        // bytes of per-key scratchpad (reference default: wf/map_gpu.hpp:141)
+    bool lanes_are_key_disjoint = false;  // batch input: lane i already holds only replica i's keys
+};
+
+// MODE 0/1: map (in place / out of place), MODE 2: filter
+template <int MODE, typename tuple_t, typename result_t, typename F>
+class KeyedGPU_Node : public GPU_Replica<tuple_t> {
+public:
+    KeyedGPU_Node(F func, KeyedGPUConfig kcfg, GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx,
+                  meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub)), func_(func), kcfg_(kcfg) {}
+
+protected:
+    void process_device(gpu::Batch* d) override {
+        hipStream_t s = this->stream();
+        if (!ctx_) ctx_.reset(new gpu::KeyedContext(kcfg_.max_keys, kcfg_.state_size, d->capacity, this->cfg_.gpu_id));
+        const size_t upper = std::max<size_t>(1, d->count_on_host ? d->host_hdr.count : d->capacity);
+        const auto sorted = ctx_->template group<tuple_t>(d, s, this->num_kernels_);
+        const unsigned grid = gpu::grid_for(upper);
+        if constexpr (MODE == 0) {
+            hipLaunchKernelGGL((gpu::keyed_apply_kernel<0, tuple_t, tuple_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
+                               d->template data<tuple_t>(), (tuple_t*)nullptr, (uint8_t*)nullptr, sorted.keys, sorted.vals, ctx_->states(),
+                               ctx_->state_size(), ctx_->table_full_counter(), func_);
+            this->num_kernels_++;
+            this->emit_device(d);
+        } else if constexpr (MODE == 1) {
+            if (!out_pool_)
+                out_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, this->cfg_.gpu_id, sizeof(result_t), d->capacity, this->cfg_.pool_slabs));
+            gpu::Batch* o = out_pool_->acquire(s);
+            WF_HIP_CHECK(hipMemcpyAsync(o->header(), d->header(), sizeof(gpu::BatchHeader), hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL((gpu::keyed_apply_kernel<1, tuple_t, result_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
+                               d->template data<tuple_t>(), o->template data<result_t>(), (uint8_t*)nullptr, sorted.keys, sorted.vals,
+                               ctx_->states(), ctx_->state_size(), ctx_->table_full_counter(), func_);
+            this->num_kernels_++;
+            o->host_hdr = d->host_hdr;
+            o->count_on_host = d->count_on_host;
+            if (!d->count_on_host)
+                WF_HIP_CHECK(hipMemcpyAsync((void*)o->count_mirror, d->device_count_ptr(), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            d->release(s);
+            this->emit_device(o);
+        } else {
+            if (!out_pool_)
+                out_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, this->cfg_.gpu_id, sizeof(tuple_t), d->capacity, this->cfg_.pool_slabs));
+            flags_.resize(d->capacity);
+            ws_.resize(gpu::filter_workspace_words(d->capacity));
+            hipLaunchKernelGGL((gpu::keyed_apply_kernel<2, tuple_t, tuple_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
+                               d->template data<tuple_t>(), (tuple_t*)nullptr, flags_.data(), sorted.keys, sorted.vals, ctx_->states(),
+                               ctx_->state_size(), ctx_->table_full_counter(), func_);
+            WF_HIP_CHECK(hipMemsetAsync(ws_.data(), 0, gpu::filter_workspace_words(upper) * sizeof(unsigned long long), s));
+            gpu::Batch* o = out_pool_->acquire(s);
+            const unsigned cgrid = (unsigned)std::max<size_t>(1, (upper + gpu::FILTER_TILE - 1) / gpu::FILTER_TILE);
+            hipLaunchKernelGGL((gpu::filter_compact_kernel<tuple_t, gpu::FlagPredicate<tuple_t>>), dim3(cgrid), dim3(gpu::BLOCK_THREADS), 0, s,
+                               d->header(), d->template data<tuple_t>(), o->header(), o->template data<tuple_t>(), o->count_mirror, ws_.data(),
+                               gpu::FlagPredicate<tuple_t>{flags_.data()});
+            this->num_kernels_ += 2;
+            o->host_hdr = d->host_hdr;
+            o->count_on_host = false;
+            d->release(s);
+            this->emit_device(o);
+        }
+    }
+    void gpu_flush() override {
+        if (ctx_ && ctx_->read_table_full(this->stream()) > 0)
+            fatal_error("keyed GPU operator: the device key table is full; raise withMaxKeys()");
+    }
+
+private:
+    F func_;
+    KeyedGPUConfig kcfg_;
+    std::unique_ptr<gpu::KeyedContext> ctx_;
+    std::unique_ptr<gpu::BatchPool> out_pool_;
+    gpu::DeviceBuffer<uint8_t> flags_;
+    gpu::DeviceBuffer<unsigned long long> ws_;
+};
+
+// Keyed operator: tuple input is routed by key on the host; batch input goes through
+// the device KeyBy emitter unless the lanes are declared key-disjoint.
+template <int MODE, typename tuple_t, typename result_t>
+class Keyed_GPU_Operator : public Basic_Operator {
+public:
+    template <typename F>
+    Keyed_GPU_Operator(F func, size_t parallelism, std::string name, KeyedGPUConfig kcfg, GPUConfig cfg, meta::closing_func_t closing,
+                       routing_func_t routing)
+        : name_(std::move(name)), par_(parallelism), kcfg_(kcfg), cfg_(cfg), routing_(std::move(routing)),
+          kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)) {
+        if (par_ == 0) fatal_error("operator " + name_ + " has parallelism zero");
+        auto hub = hub_;
+        const std::string n = name_;
+        const size_t N = par_;
+        factory_ = [=](rt::Graph& g, edge_kind_t node_kind) {
+            std::vector<rt::Node*> reps;
+            for (size_t i = 0; i < N; i++)
+                reps.push_back(g.adopt(new KeyedGPU_Node<MODE, tuple_t, result_t, F>(func, kcfg, cfg, node_kind, n, N, i, closing, hub)));
+            return reps;
+        };
+    }
+    std::string getName() const override { return name_; }
+    size_t getParallelism() const override { return par_; }
+    routing_modes_t getRoutingMode() const override { return KEYBY; }
+    bool isGPUOperator() const override { return true; }
+    const std::type_info& input_type() const override { return typeid(tuple_t); }
+    const std::type_info& output_type() const override { return typeid(result_t); }
+    edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
+    bool accepts_input_kind(edge_kind_t) const override { return true; }
+    void set_input_kind(edge_kind_t k) override { *kind_ = k; }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(cfg_.pool_slabs); }
+
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
+        StageSpec s;
+        s.name = name_;
+        const size_t N = par_;
+        const edge_kind_t kind = *kind_;
+        if (kind == EDGE_TUPLE) {
+            s.routing = KEYBY;
+            s.replicas = factory_(g, EDGE_TUPLE);
+            routing_func_t rf = routing_;
+            s.make_emitter = [rf, N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(rf, N), N); };
+            s.make_ordering = [](Mode m) -> rt::Node* { return m == Mode::DETERMINISTIC ? new Ordering_Node<tuple_t>(TS) : nullptr; };
+        } else if (kcfg_.lanes_are_key_disjoint) {
+            s.routing = FORWARD;
+            s.replicas = factory_(g, kind);
+            s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
+        } else {
+            s.routing = KEYBY;
+            s.replicas = factory_(g, EDGE_DEVICE_BATCH);  // the emitter ships host batches to the device itself
+            const int dev = cfg_.gpu_id;
+            const size_t slabs = cfg_.pool_slabs;
+            s.make_emitter = [N, kind, dev, slabs](rt::Graph& gr, size_t) {
+                return single_emitter(gr, new KeyBy_EmitterGPU<tuple_t>(N, kind, dev, slabs), N);
+            };
+        }
+        return {s};
+    }
+
+private:
+    std::string name_;
+    size_t par_;
+    KeyedGPUConfig kcfg_;
+    GPUConfig cfg_;
+    routing_func_t routing_;
+    std::shared_ptr<edge_kind_t> kind_;
+    std::function<std::vector<rt::Node*>(rt::Graph&, edge_kind_t)> factory_;
+};
+
+}  // namespace wf

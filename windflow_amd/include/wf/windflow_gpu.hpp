@@ -11,4 +11,6 @@
 #include "gpu/flatfat_gpu.hpp"
 #include "gpu/key_ffat_gpu.hpp"
 #include "gpu/win_seq_gpu.hpp"
+#include "gpu/keyby_gpu.hpp"
+#include "gpu/keyed_gpu.hpp"
 #include "builders_gpu.hpp"
