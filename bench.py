@@ -44,7 +44,46 @@ def parse_args():
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
                    help="tuples fed per GPU per step")
     p.add_argument("--inflight", type=int, default=6)
+    p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "dp"), choices=["dp", "keyby"],
+                   help="dp: keys are partitioned at ingestion, every GPU aggregates its own sources; "
+                        "keyby: tuples are re-partitioned by key across GPUs with Exchange_GPU (RCCL all-to-all over xGMI)")
+    p.add_argument("--exchange-probe-steps", type=int, default=int(os.environ.get("WF_BENCH_EXCHANGE_PROBE", "3")),
+                   help="N>1, dp mode: after the timed run, also time this many steps of the keyby pipeline (reported as an "
+                        "extra field; 0 disables)")
     return p.parse_args()
+
+
+def timed_steps(pipe, per_source, steps, barrier):
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(per_source)
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def run_guarded(fn, timeout_s):
+    """Run fn() in a thread; returns (finished, result_or_exception)."""
+    import threading
+
+    box = {}
+
+    def body():
+        try:
+            box["r"] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box["e"] = e
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return False, None
+    if "e" in box:
+        return True, box["e"]
+    return True, box["r"]
 
 
 def main():
@@ -73,7 +112,13 @@ def main():
         else:
             # one tuple per microsecond per source, keys round-robin: a key ticks every keys_per_source us
             win, slide = args.win * keys_per_source, args.slide * keys_per_source
-        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0, args.inflight)
+        transport = None
+        if args.parallelism == "keyby":
+            from windflow_amd import parallel as wfpar
+
+            transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
+        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0, args.inflight,
+                                  transport)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 
@@ -84,23 +129,46 @@ def main():
     for _ in range(args.warmup):
         pipe.step(per_source)
     pipe.reset_latency()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step(per_source)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(pipe, per_source, args.steps, barrier)
     stats = pipe.stats()
     pipe.close()
-
     t = torch.tensor([elapsed], dtype=torch.float64)
     lat = torch.tensor([stats["latency_p99_us"]], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(lat, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # Secondary measurement (never part of `value`): the same job with the cross-GPU KeyBy exchange in the
+    # data path.  Guarded by a wall-clock limit so that a fabric problem cannot take the headline number down.
+    probe = None
+    hung = False
+    if (world > 1 or os.environ.get("WF_BENCH_FORCE_PROBE")) and args.pipeline == "win_agg" and args.parallelism == "dp" \
+            and args.exchange_probe_steps > 0:
+        def exchange_probe():
+            from windflow_amd import parallel as wfpar
+
+            tr = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
+            p2 = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0,
+                                    args.inflight, tr)
+            p2.step(per_source)
+            el = timed_steps(p2, per_source, args.exchange_probe_steps, barrier)
+            st = p2.stats()
+            p2.close()
+            return el, st
+
+        finished, r = run_guarded(exchange_probe, 150.0)
+        if not finished:
+            hung = True
+            probe = {"status": "timeout"}
+        elif isinstance(r, BaseException):
+            probe = {"status": "error: %s" % (r,)}
+        else:
+            el = r[0]
+            probe = {"status": "ok", "tuples_per_s": tuples_per_step_gpu * world * args.exchange_probe_steps / el,
+                     "steps": args.exchange_probe_steps, "p99_latency_us": r[1]["latency_p99_us"]}
+
+
     if rank == 0:
         total_tuples = tuples_per_step_gpu * world * args.steps
         value = total_tuples / elapsed
@@ -124,7 +192,7 @@ def main():
                 "model": "Key_FFAT_GPU keyed sliding-window sum" if args.pipeline == "win_agg" else args.pipeline,
                 "global_batch": tuples_per_step_gpu * world,
                 "seq_len": args.batch,
-                "parallelism": "dp%d" % world,
+                "parallelism": "%s%d" % (args.parallelism, world),
                 "sources_per_gpu": args.sources,
                 "keys_per_gpu": keys_per_source * args.sources,
                 "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if args.count_based else "TB", args.win, args.slide),
@@ -132,7 +200,12 @@ def main():
                 "overflow": stats.get("overflow", 0),
                 "dropped": stats.get("dropped", 0),
             },
+            **({"keyby_exchange_probe": probe} if probe is not None else {}),
         }), flush=True)
+    if hung:
+        # a rank is still blocked inside a collective: leave without running destructors
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

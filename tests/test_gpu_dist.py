@@ -1,0 +1,90 @@
+"""Distributed layer on one GPU: in-process multi-rank exchange (LocalTransport), RCCL with world size 1."""
+import math
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,n,keys,batch", [(2, 40_000, 101, 2048), (3, 60_000, 1000, 4096), (4, 30_000, 7, 1024)])
+def test_exchange_conserves_and_routes(ext, world, n, keys, batch):
+    res = ext.exchange_local_run(0, world, n, keys, batch)
+    sent = [n * (r + 1) // world for r in range(world)]
+    assert sum(r[0] for r in res) == sum(sent)
+    exp_sum = sum(float(np.sum(np.arange(s) % 97)) for s in sent)
+    assert sum(r[1] for r in res) == pytest.approx(exp_sum)
+    assert all(r[2] == 0 for r in res), "tuples delivered to a rank that does not own their key"
+    assert all(r[3] == 0 for r in res), "per-key FIFO order broken by the exchange"
+    if keys >= 100:
+        assert all(r[0] > 0 for r in res)
+
+
+def test_rccl_world1_collectives(ext):
+    uid = ext.rccl_create_id()
+    tr = ext.rccl_transport(0, 1, uid, 0)
+    assert (tr.rank, tr.world, tr.name) == (0, 1, "rccl")
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    tr.all_reduce_sum(x.data_ptr(), x.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+    assert tr.all_gather([7, 8, 9]) == [7, 8, 9]
+    tr.barrier()
+
+
+def _expected_single_source(n, n_keys, win, slide):
+    per_key = n // n_keys
+    vals = (np.arange(n) & 1023).astype(np.float64)
+    total, windows = 0.0, 0
+    for k in range(n_keys):
+        v = vals[k::n_keys]
+        c = np.concatenate([[0.0], np.cumsum(v)])
+        for lw in range(math.ceil(per_key / slide)):
+            total += c[min(per_key, slide * lw + win)] - c[slide * lw]
+            windows += 1
+    return total, windows
+
+
+def _run_ranks(ext, world, make_transport, n_sources=2, n_keys=50, per_source=40_000):
+    stats = [None] * world
+    errors = []
+
+    def rank_main(r):
+        try:
+            pipe = ext.WinAggPipeline(0, n_sources, 4096, n_keys, 8, 2, False, 0, 4, make_transport(r))
+            pipe.step(per_source)
+            pipe.step(per_source)
+            pipe.close()
+            stats[r] = pipe.stats()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors
+    assert all(s is not None for s in stats)
+    return stats
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_win_agg_with_cross_rank_exchange(ext, world):
+    fabric = ext.LocalFabric(world)
+    stats = _run_ranks(ext, world, lambda r: ext.local_transport(fabric, r))
+    total, windows = _expected_single_source(2 * 40_000, 50, 8, 2)
+    assert sum(s["sink_tuples"] for s in stats) == world * 2 * windows
+    assert sum(s["sink_value_sum"] for s in stats) == pytest.approx(world * 2 * total, rel=1e-12)
+    assert all(s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
+    assert all(s["sink_tuples"] > 0 for s in stats)
+
+
+def test_win_agg_with_rccl_world1(ext):
+    uid = ext.rccl_create_id()
+    stats = _run_ranks(ext, 1, lambda r: ext.rccl_transport(0, 1, uid, 0))
+    total, windows = _expected_single_source(2 * 40_000, 50, 8, 2)
+    assert stats[0]["sink_tuples"] == 2 * windows
+    assert stats[0]["sink_value_sum"] == pytest.approx(2 * total, rel=1e-12)

@@ -103,8 +103,10 @@ struct StepBarrier {
 // a monotone per-source microsecond clock.
 class GatedGenerator {
 public:
-    GatedGenerator(StepGate* gates, size_t n_keys, uint64_t ts_step_us, size_t n_sources)
-        : gates_(gates), n_keys_(n_keys), ts_step_(ts_step_us), n_sources_(n_sources) {}
+    // src_offset / src_stride: position of this process's sources among all the sources of the job
+    // (rank * n_sources, world * n_sources), so keys stay disjoint across ranks as well
+    GatedGenerator(StepGate* gates, size_t n_keys, uint64_t ts_step_us, size_t n_sources, size_t src_offset = 0, size_t src_stride = 0)
+        : gates_(gates), n_keys_(n_keys), ts_step_(ts_step_us), n_sources_(src_stride ? src_stride : n_sources), src_offset_(src_offset) {}
 
     bool operator()(tuple_t* buf, size_t cap, size_t& n, wf::RuntimeContext& ctx) {
         StepGate& g = gates_[ctx.getReplicaIndex()];
@@ -122,7 +124,7 @@ public:
             if (g.quota == 0) punct_ = g.step_id;  // last batch of the step
         }
         opened_ns_ = wf::current_time_nsecs();
-        const uint64_t src = ctx.getReplicaIndex();
+        const uint64_t src = ctx.getReplicaIndex() + src_offset_;
         uint64_t seq = seq_, kc = kc_, round = round_;
         const uint64_t nk = n_keys_, ns = n_sources_, tstep = ts_step_;
         // keys of different sources are disjoint (key % n_sources == src): per-key order is
@@ -154,6 +156,7 @@ private:
     size_t n_keys_;
     uint64_t ts_step_;
     size_t n_sources_;
+    size_t src_offset_ = 0;
     uint64_t seq_ = 0, kc_ = 0, round_ = 0;
     uint64_t punct_ = 0;
     uint64_t opened_ns_ = 0;

@@ -7,8 +7,10 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <wf/windflow.hpp>
@@ -268,12 +270,16 @@ static uint32_t exclusive_scan(uintptr_t in, uintptr_t out, size_t n) {
 // (BASELINE.json config 4, the flagship "sliding-window aggregation" pipeline)
 class WinAggPipeline {
 public:
+    // transport == nullptr: every source lane feeds its own Key_FFAT_GPU replica (keys are partitioned at the
+    // sources).  With a transport the tuples are re-partitioned by key across the ranks first (Exchange_GPU:
+    // RCCL all-to-all over xGMI) and then across the local replicas (device KeyBy).
     WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
-                   size_t inflight)
+                   size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr)
         : n_sources_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<SinkTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
-        wfbench::GatedGenerator gen(gates_.get(), n_keys, 1, n_sources);
+        const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
+        wfbench::GatedGenerator gen(gates_.get(), n_keys, 1, n_sources, rank * n_sources, world * n_sources);
         source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
                       .withGPUConfiguration(gpu_id).build_unique();
         MultiPipe& mp = graph_.add_source(*source_);
@@ -289,6 +295,16 @@ public:
         cfg.gpu_id = gpu_id;
         cfg.batch_len = batch_len;
         cfg.pool_slabs = inflight;
+        if (transport) {
+            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withLocalLanes(n_sources).withGPUConfiguration(gpu_id)
+                            .withInFlightBatches(inflight).build_unique();
+            mp.add(*exchange_);
+            wcfg.lanes_are_key_disjoint = false;
+            // hash partitioning is only balanced on average: leave headroom in the per-replica key tables and
+            // in the result batches (a replica may see up to world x batch_len tuples in one batch)
+            wcfg.max_keys = n_keys + n_keys / 4 + 1024;
+            wcfg.out_capacity = batch_len * world;
+        }
         kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sources, "key_ffat_gpu", cfg));
         mp.add(*kff_);
         auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
@@ -357,11 +373,89 @@ private:
     std::shared_ptr<wfbench::StepBarrier> barrier_;
     std::shared_ptr<LatencyRecorder> latency_;
     std::unique_ptr<Batch_Source<tuple_t>> source_;
+    std::unique_ptr<Exchange_GPU<tuple_t>> exchange_;
     std::unique_ptr<Key_FFAT_GPU<tuple_t, result_t>> kff_;
     std::unique_ptr<Batch_Sink<result_t>> sink_;
     uint64_t step_id_ = 0;
     bool closed_ = false;
 };
+
+// ---------------------------------------------------------------------------
+// distributed layer
+// ---------------------------------------------------------------------------
+static py::bytes rccl_create_id() { return py::bytes(dist::RcclTransport::create_id()); }
+
+static std::shared_ptr<dist::Transport> make_rccl_transport(int rank, int world, const std::string& id, int device) {
+    py::gil_scoped_release rel;
+    return std::make_shared<dist::RcclTransport>(rank, world, id, device);
+}
+
+// sum of a device buffer of doubles across ranks (in place), synchronous
+static void transport_all_reduce_sum(dist::Transport& t, uintptr_t dev, size_t n) {
+    check_ptr(dev, "dev");
+    py::gil_scoped_release rel;
+    gpu::Stream s;
+    t.all_reduce_sum(reinterpret_cast<double*>(dev), n, s);
+    s.sync();
+}
+
+static std::vector<uint64_t> transport_all_gather(dist::Transport& t, const std::vector<uint64_t>& mine) {
+    std::vector<uint64_t> out(mine.size() * (size_t)t.world());
+    py::gil_scoped_release rel;
+    gpu::Stream s;
+    t.all_gather_host(mine.data(), out.data(), mine.size(), s);
+    return out;
+}
+
+// Exchange_GPU conservation check: `world` in-process ranks (threads) on one device, each runs
+//   Batch_Source(n tuples, keys of its own) -> Exchange_GPU(LocalTransport) -> Batch_Sink
+// returns per rank {tuples received, value sum, tuples not owned by the rank, per-key order violations, rounds}
+static std::vector<std::vector<double>> exchange_local_run(int gpu_id, int world, size_t n_per_rank, size_t n_keys, size_t batch_len) {
+    py::gil_scoped_release rel;
+    auto fabric = std::make_shared<dist::LocalFabric>(world);
+    std::vector<std::vector<double>> res((size_t)world, std::vector<double>(4, 0.0));
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; r++) {
+        threads.emplace_back([&, r] {
+            auto tr = std::make_shared<dist::LocalTransport>(fabric, r);
+            PipeGraph g("exchange_rank" + std::to_string(r), Mode::DEFAULT);
+            size_t sent = 0;
+            // rank r produces (r+1)/world of n_per_rank tuples: uneven streams exercise the end-of-stream rounds
+            const size_t n = n_per_rank * (size_t)(r + 1) / (size_t)world;
+            auto gen = [=](tuple_t& t) mutable {
+                t.key = (sent % n_keys) * (size_t)world + (size_t)r;  // keys of different ranks are disjoint
+                t.id = sent / n_keys;
+                t.ts = sent;
+                t.value = (double)(sent % 97);
+                t.aux = (double)r;
+                sent++;
+                return sent < n;
+            };
+            auto src = BatchSource_Builder(gen).withName("src").withParallelism(1).withBatch(batch_len).withGPUConfiguration(gpu_id).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto ex = ExchangeGPU_Builder<tuple_t>(tr).withGPUConfiguration(gpu_id).build_unique();
+            mp.add(*ex);
+            std::map<uint64_t, uint64_t> last_id;
+            std::vector<double>* out = &res[(size_t)r];
+            const uint32_t W = (uint32_t)world;
+            auto sink_f = [out, W, r, last_id](const tuple_t* data, size_t cnt) mutable {
+                for (size_t i = 0; i < cnt; i++) {
+                    (*out)[0] += 1;
+                    (*out)[1] += data[i].value;
+                    if (gpu::keyby_destination(data[i].key, W, gpu::HASH_SHIFT_RANKS) != (uint32_t)r) (*out)[2] += 1;
+                    auto it = last_id.find(data[i].key);
+                    if (it != last_id.end() && data[i].id <= it->second) (*out)[3] += 1;
+                    last_id[data[i].key] = data[i].id;
+                }
+            };
+            auto sink = BatchSink_Builder(sink_f).withName("sink").withParallelism(1).build_unique();
+            mp.add_sink(*sink);
+            g.run();
+        });
+    }
+    for (auto& t : threads) t.join();
+    return res;
+}
 
 PYBIND11_MODULE(_C, m) {
     m.doc() = "windflow_amd native extension (gfx950)";
@@ -373,10 +467,29 @@ PYBIND11_MODULE(_C, m) {
           py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0);
     m.def("radix_sort_pairs", &radix_sort_pairs, py::arg("keys"), py::arg("vals"), py::arg("n"), py::arg("bits"));
     m.def("exclusive_scan", &exclusive_scan, py::arg("inp"), py::arg("out"), py::arg("n"));
+    py::class_<dist::Transport, std::shared_ptr<dist::Transport>>(m, "Transport")
+        .def_property_readonly("rank", &dist::Transport::rank)
+        .def_property_readonly("world", &dist::Transport::world)
+        .def_property_readonly("name", [](dist::Transport& t) { return std::string(t.name()); })
+        .def("all_reduce_sum", &transport_all_reduce_sum, py::arg("dev_ptr"), py::arg("n"))
+        .def("all_gather", &transport_all_gather, py::arg("words"))
+        .def("barrier", [](dist::Transport& t) {
+            py::gil_scoped_release rel;
+            gpu::Stream s;
+            t.barrier(s);
+        });
+    py::class_<dist::LocalFabric, std::shared_ptr<dist::LocalFabric>>(m, "LocalFabric").def(py::init<int>(), py::arg("world"));
+    m.def("rccl_create_id", &rccl_create_id);
+    m.def("rccl_transport", &make_rccl_transport, py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("device"));
+    m.def("local_transport", [](std::shared_ptr<dist::LocalFabric> f, int rank) -> std::shared_ptr<dist::Transport> {
+        return std::make_shared<dist::LocalTransport>(std::move(f), rank);
+    }, py::arg("fabric"), py::arg("rank"));
+    m.def("exchange_local_run", &exchange_local_run, py::arg("gpu_id"), py::arg("world"), py::arg("n_per_rank"), py::arg("n_keys"),
+          py::arg("batch_len"));
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
-        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"),
-             py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"), py::arg("time_based") = false, py::arg("delay") = 0,
-             py::arg("inflight") = 6)
+        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>>(), py::arg("gpu_id"),
+             py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"), py::arg("time_based") = false,
+             py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr)
         .def("step", &WinAggPipeline::step)
         .def("close", &WinAggPipeline::close)
         .def("stats", &WinAggPipeline::stats)

@@ -1,0 +1,253 @@
+// Exchange_GPU: KeyBy across GPUs.  Every rank (process or thread owning one GPU)
+// places one Exchange_GPU in its MultiPipe; batches entering it are partitioned by
+// key on the device and re-distributed with one all-to-all per round, so that a key
+// is only ever seen by the rank that owns it (owner = bits 48-63 of mix64(key) mod
+// world).  Downstream keyed operators (Key_FFAT_GPU, keyed Map_GPU ...) then run
+// unchanged on purely local state.
+//
+// No counterpart in the reference (single process, no inter-GPU traffic, SURVEY.md
+// §2.6); this is the piece that turns "N replicas on N GPUs" into a scalable
+// one-process-per-GPU deployment over xGMI.
+//
+// Protocol (all ranks run the same sequence of collectives, in lock step):
+//   round:  1. partition my batch (possibly empty) into `world` device sub-batches
+//           2. all-gather {counts[world], done, step punctuation, watermark}
+//           3. all-to-all-v with the exact sizes learned in 2; slices land
+//              rank-major in one output batch, so per-key order is (round, source
+//              rank, position): FIFO per producer is preserved
+//           4. emit the output batch (count known on the host, no further sync)
+//   a rank without input contributes an empty round (from on_idle, rate limited);
+//   at end of stream a rank keeps contributing empty rounds with done = 1 until
+//   every rank is done.  Step punctuations (header.reserved[0], see Batch_Source)
+//   are delivered downstream once every rank has reported them.
+#pragma once
+#include <cstddef>
+#include <map>
+
+#include "../builders_gpu.hpp"
+#include "../gpu/keyby_gpu.hpp"
+#include "transport.hpp"
+
+namespace wf {
+
+struct ExchangeConfig {
+    size_t local_lanes = 1;         // producers feeding this exchange on this rank (punctuations to wait for per step)
+    uint64_t idle_round_us = 200;   // with no input, contribute an empty round this often
+};
+
+template <typename tuple_t>
+class ExchangeGPU_Node : public GPU_Replica<tuple_t> {
+public:
+    ExchangeGPU_Node(std::shared_ptr<dist::Transport> tr, ExchangeConfig xcfg, GPUConfig cfg, edge_kind_t in_kind, std::string name,
+                     meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), 1, 0, std::move(closing), std::move(hub)), tr_(std::move(tr)), xcfg_(xcfg) {
+        if (!tr_) gpu::failwith("Exchange_GPU: no transport");
+        if (tr_->world() > gpu::MAX_PARTITIONS) gpu::failwith("Exchange_GPU: world size above MAX_PARTITIONS");
+    }
+    bool wants_idle() const override { return tr_->world() > 1; }
+    void on_idle() override {
+        if (finished_) return;
+        const uint64_t now = current_time_usecs();
+        if (now - last_round_us_ < xcfg_.idle_round_us) return;
+        round(nullptr, false);
+    }
+    uint64_t rounds() const { return rounds_; }
+
+protected:
+    void gpu_init() override {
+        part_.reset(new gpu::BatchPartitioner<tuple_t>((size_t)tr_->world(), this->cfg_.gpu_id, 2, gpu::HASH_SHIFT_RANKS));
+        last_round_us_ = current_time_usecs();
+    }
+    void process_device(gpu::Batch* d) override { round(d, false); }
+    void gpu_flush() override {
+        // end of my stream: keep serving rounds until everybody is done
+        while (!finished_) round(nullptr, true);
+    }
+
+private:
+    static constexpr size_t META = gpu::MAX_PARTITIONS + 5;  // counts[], done, step, watermark, created_ns, batch capacity
+
+    void round(gpu::Batch* d, bool done) {
+        const int world = tr_->world(), me = tr_->rank();
+        hipStream_t s = this->stream();
+        std::vector<gpu::Batch*> parts;
+        uint64_t mine[META] = {};
+        if (d != nullptr) {
+            my_cap_ = std::max(my_cap_, d->capacity);
+            if (d->host_hdr.reserved[0] != 0) note_local_punctuation(d->host_hdr.reserved[0]);
+            if (world == 1) {  // nothing to exchange: pass through (punctuations are still merged over the local lanes)
+                const uint64_t step = take_global_step(local_step_done_);
+                if (step != d->host_hdr.reserved[0]) {
+                    d->host_hdr.reserved[0] = step;
+                    WF_HIP_CHECK(hipMemcpyAsync(d->slab + offsetof(gpu::BatchHeader, reserved), &d->host_hdr.reserved[0], sizeof(uint64_t),
+                                                hipMemcpyHostToDevice, s));
+                }
+                this->emit_device(d);
+                return;
+            }
+            part_->partition(d, s, parts, this->num_kernels_);
+            mine[gpu::MAX_PARTITIONS + 2] = d->host_hdr.watermark;
+            mine[gpu::MAX_PARTITIONS + 3] = d->host_hdr.created_ns;
+            d->release(s);
+            // the sub-batch counts are needed on the host to size the exchange
+            WF_HIP_CHECK(hipStreamSynchronize(s));
+            for (int p = 0; p < world; p++) mine[p] = *parts[p]->count_mirror;
+        } else if (world == 1) {
+            finished_ = done;
+            return;
+        }
+        mine[gpu::MAX_PARTITIONS + 0] = done ? 1 : 0;
+        mine[gpu::MAX_PARTITIONS + 1] = local_step_done_;
+        mine[gpu::MAX_PARTITIONS + 4] = my_cap_;
+        uint64_t all[META * dist::MAX_WORLD];
+        tr_->all_gather_host(mine, all, META, s);
+        // what I receive, rank-major
+        size_t total = 0;
+        bool all_done = true;
+        uint64_t min_step = UINT64_MAX, wm = 0, created = 0;
+        size_t recv_cnt[dist::MAX_WORLD];
+        for (int r = 0; r < world; r++) {
+            const uint64_t* row = all + (size_t)r * META;
+            recv_cnt[r] = (size_t)row[me];
+            total += recv_cnt[r];
+            all_done = all_done && row[gpu::MAX_PARTITIONS + 0] != 0;
+            min_step = std::min(min_step, row[gpu::MAX_PARTITIONS + 1]);
+            wm = std::max(wm, row[gpu::MAX_PARTITIONS + 2]);
+            cap_ = std::max<size_t>(cap_, (size_t)row[gpu::MAX_PARTITIONS + 4]);
+            if (row[gpu::MAX_PARTITIONS + 3] != 0 && recv_cnt[r] > 0) created = created == 0 ? row[gpu::MAX_PARTITIONS + 3] : std::min(created, row[gpu::MAX_PARTITIONS + 3]);
+        }
+        bool any_traffic = false;
+        for (int r = 0; r < world && !any_traffic; r++)
+            for (int p = 0; p < world; p++)
+                if (all[(size_t)r * META + p] != 0) {
+                    any_traffic = true;
+                    break;
+                }
+        const uint64_t step_out = take_global_step(min_step);
+        gpu::Batch* out = nullptr;
+        if (any_traffic) {
+            if (total > 0 || step_out != 0) out = acquire_out(total);
+            dist::PeerSlices sl;
+            size_t off = 0;
+            for (int p = 0; p < world; p++) {
+                if (!parts.empty()) {
+                    sl.send[p] = parts[p]->template data<tuple_t>();
+                    sl.send_bytes[p] = (size_t)mine[p] * sizeof(tuple_t);
+                }
+                if (recv_cnt[p] > 0) {
+                    sl.recv[p] = out->template data<tuple_t>() + off;
+                    sl.recv_bytes[p] = recv_cnt[p] * sizeof(tuple_t);
+                    off += recv_cnt[p];
+                }
+            }
+            tr_->all_to_all_v(sl, s);
+            bytes_exchanged_ += off * sizeof(tuple_t);
+        } else if (step_out != 0) {
+            out = acquire_out(0);
+        }
+        for (gpu::Batch* p : parts) p->release(s);
+        if (out != nullptr) {
+            out->host_hdr.count = (uint32_t)total;
+            out->host_hdr.source_id = (uint32_t)me;
+            out->host_hdr.watermark = wm;
+            out->host_hdr.created_ns = created;
+            out->host_hdr.first_seq = seq_;
+            out->host_hdr.reserved[0] = step_out;
+            out->count_on_host = true;
+            seq_ += total;
+            WF_HIP_CHECK(hipMemcpyAsync(out->slab, &out->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, s));
+            this->emit_device(out);
+        }
+        rounds_++;
+        last_round_us_ = current_time_usecs();
+        if (all_done && !any_traffic) finished_ = true;
+    }
+
+    gpu::Batch* acquire_out(size_t total) {
+        // worst case every rank sends me a full batch (cap_ = largest batch capacity announced by any rank)
+        const size_t need = std::max<size_t>(std::max(cap_ * (size_t)tr_->world(), total), 1);
+        if (!out_pool_ || out_cap_ < need) {
+            // batches of the old pool may still be in flight downstream: keep it alive until the end
+            if (out_pool_) retired_pools_.push_back(std::move(out_pool_));
+            out_cap_ = need;
+            out_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, this->cfg_.gpu_id, sizeof(tuple_t), out_cap_, this->cfg_.pool_slabs));
+        }
+        return out_pool_->acquire(this->stream());
+    }
+
+    // a step is locally complete when every local lane has punctuated it
+    void note_local_punctuation(uint64_t step) {
+        if (++punct_seen_[step] >= xcfg_.local_lanes) {
+            local_step_done_ = std::max(local_step_done_, step);
+            punct_seen_.erase(step);
+        }
+    }
+    // returns the step id to announce downstream (0: none) given the minimum step all ranks completed
+    uint64_t take_global_step(uint64_t min_step) {
+        if (min_step != UINT64_MAX && min_step > announced_step_) {
+            announced_step_ = min_step;
+            return min_step;
+        }
+        return 0;
+    }
+
+    std::shared_ptr<dist::Transport> tr_;
+    ExchangeConfig xcfg_;
+    std::unique_ptr<gpu::BatchPartitioner<tuple_t>> part_;
+    std::unique_ptr<gpu::BatchPool> out_pool_;
+    std::vector<std::unique_ptr<gpu::BatchPool>> retired_pools_;
+    size_t my_cap_ = 0, cap_ = 0, out_cap_ = 0;
+    uint64_t seq_ = 0, rounds_ = 0, bytes_exchanged_ = 0, last_round_us_ = 0;
+    uint64_t local_step_done_ = 0, announced_step_ = 0;
+    std::map<uint64_t, size_t> punct_seen_;
+    bool finished_ = false;
+};
+
+// The operator: parallelism is always 1 per rank (the rank's endpoint on the fabric).
+template <typename tuple_t>
+class Exchange_GPU : public Simple_Operator<tuple_t, tuple_t> {
+public:
+    Exchange_GPU(std::shared_ptr<dist::Transport> transport, std::string name = "exchange_gpu", GPUConfig cfg = GPUConfig(),
+                 ExchangeConfig xcfg = ExchangeConfig(), meta::closing_func_t closing = nullptr)
+        : Simple_Operator<tuple_t, tuple_t>(name, 1, FORWARD, nullptr, nullptr), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)), slabs_(cfg.pool_slabs) {
+        auto kind = kind_;
+        this->factory_ = [transport, xcfg, cfg, kind, name, closing](size_t, size_t, std::shared_ptr<StatsHub> hub) -> rt::Node* {
+            return new ExchangeGPU_Node<tuple_t>(transport, xcfg, cfg, *kind, name, closing, std::move(hub));
+        };
+    }
+    bool isGPUOperator() const override { return true; }
+    edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
+    bool accepts_input_kind(edge_kind_t) const override { return true; }
+    void set_input_kind(edge_kind_t k) override { *kind_ = k; }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<tuple_t>(slabs_); }
+
+private:
+    std::shared_ptr<edge_kind_t> kind_;
+    size_t slabs_;
+};
+
+template <typename tuple_t>
+class ExchangeGPU_Builder : public GPU_Builder_Base<ExchangeGPU_Builder<tuple_t>> {
+public:
+    explicit ExchangeGPU_Builder(std::shared_ptr<dist::Transport> transport)
+        : GPU_Builder_Base<ExchangeGPU_Builder<tuple_t>>("exchange_gpu"), transport_(std::move(transport)) {}
+    // number of local producers whose step punctuations are merged (see Batch_Source)
+    ExchangeGPU_Builder& withLocalLanes(size_t n) {
+        xcfg_.local_lanes = n;
+        return *this;
+    }
+    ExchangeGPU_Builder& withIdleRoundInterval(uint64_t usec) {
+        xcfg_.idle_round_us = usec;
+        return *this;
+    }
+    Exchange_GPU<tuple_t> build() { return Exchange_GPU<tuple_t>(transport_, this->name_, this->cfg_, xcfg_, this->closing_); }
+    std::unique_ptr<Exchange_GPU<tuple_t>> build_unique() {
+        return std::make_unique<Exchange_GPU<tuple_t>>(transport_, this->name_, this->cfg_, xcfg_, this->closing_);
+    }
+
+private:
+    std::shared_ptr<dist::Transport> transport_;
+    ExchangeConfig xcfg_;
+};
+
+}  // namespace wf

@@ -18,6 +18,8 @@ namespace wf {
 namespace gpu {
 
 constexpr int MAX_PARTITIONS = 16;
+constexpr uint32_t HASH_SHIFT_LANES = 24;
+constexpr uint32_t HASH_SHIFT_RANKS = 48;
 
 template <typename T>
 struct DestTable {
@@ -64,7 +66,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 template <typename T>
 class BatchPartitioner {
 public:
-    BatchPartitioner(size_t n_dest, int device, size_t pool_slabs) : n_dest_(n_dest), device_(device), pool_slabs_(pool_slabs) {
+    // hash_shift selects which 24 bits of mix64(key) pick the destination.  Every level that divides the key space
+    // must use bits of its own or the inner level sees a single residue class: the device key tables use the low
+    // bits, lanes inside a GPU use bits 24-47 (HASH_SHIFT_LANES), ranks use bits 48-63 (HASH_SHIFT_RANKS).
+    BatchPartitioner(size_t n_dest, int device, size_t pool_slabs, uint32_t hash_shift = HASH_SHIFT_LANES)
+        : n_dest_(n_dest), device_(device), pool_slabs_(pool_slabs), hash_shift_(hash_shift) {
         if (n_dest_ == 0 || n_dest_ > (size_t)MAX_PARTITIONS) failwith("BatchPartitioner: unsupported number of destinations");
         bits_ = 1;
         while ((1u << bits_) < n_dest_) bits_++;
@@ -92,7 +98,7 @@ public:
         }
         const unsigned grid = grid_for(std::max<size_t>(upper, 1));
         hipLaunchKernelGGL((dest_keys_kernel<T, KeyOfAny>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                           (uint32_t)n_dest_, dest_.data(), idx_.data(), KeyOfAny{});
+                           (uint32_t)n_dest_, dest_.data(), idx_.data(), KeyOfAny{}, hash_shift_);
         const auto sorted = sorter_.sort(dest_.data(), idx_.data(), in->device_count_ptr(), std::max<size_t>(upper, 1), bits_, s);
         hipLaunchKernelGGL(partition_offsets_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), sorted.keys, (uint32_t)n_dest_,
                            offsets_.data());
@@ -109,6 +115,7 @@ private:
     size_t n_dest_;
     int device_;
     size_t pool_slabs_;
+    uint32_t hash_shift_;
     int bits_ = 1;
     std::unique_ptr<BatchPool> pool_;
     DeviceBuffer<uint32_t> dest_, idx_, offsets_;
@@ -116,7 +123,9 @@ private:
 };
 
 // destination of a key under the device KeyBy (host code can call it too)
-__host__ __device__ inline uint32_t keyby_destination(uint64_t key, uint32_t n_dest) { return (uint32_t)(mix64(key) % n_dest); }
+__host__ __device__ inline uint32_t keyby_destination(uint64_t key, uint32_t n_dest, uint32_t hash_shift = HASH_SHIFT_LANES) {
+    return (uint32_t)(((mix64(key) >> hash_shift) & 0xffffffull) % n_dest);
+}
 
 }  // namespace gpu
 

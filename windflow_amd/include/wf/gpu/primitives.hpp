@@ -339,10 +339,10 @@ private:
 // ---------------------------------------------------------------------------
 template <typename T, typename KeyFn>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    dest_keys_kernel(const BatchHeader* hdr, const T* data, uint32_t n_dest, uint32_t* dest, uint32_t* idx, KeyFn keyfn) {
+    dest_keys_kernel(const BatchHeader* hdr, const T* data, uint32_t n_dest, uint32_t* dest, uint32_t* idx, KeyFn keyfn, uint32_t hash_shift = 24) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        dest[i] = (uint32_t)(mix64((uint64_t)keyfn(data[i])) % n_dest);
+        dest[i] = (uint32_t)(((mix64((uint64_t)keyfn(data[i])) >> hash_shift) & 0xffffffull) % n_dest);
         idx[i] = i;
     }
 }

@@ -14,3 +14,5 @@
 #include "gpu/keyby_gpu.hpp"
 #include "gpu/keyed_gpu.hpp"
 #include "builders_gpu.hpp"
+#include "dist/transport.hpp"
+#include "dist/exchange_gpu.hpp"
