@@ -1,0 +1,43 @@
+"""Applications built on the library: Yahoo! Streaming Benchmark (CPU Key_Farm / Win_MapReduce versions, GPU version).
+
+Counted mode (-e) makes the stream deterministic: every source emits N events 10 us apart, one third are views,
+all ads are known, windows are 10 s tumbling per campaign (100 campaigns)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from windflow_amd import build as wfbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_app(name, args, hip=False, timeout=110):
+    src = os.path.join(ROOT, "apps", "ysb", name + (".hip" if hip else ".cpp"))
+    exe = wfbuild.build_cpp(src, os.path.join(ROOT, "apps", "bin", name), hip=hip, extra=["-I" + os.path.dirname(src)])
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = {}
+    for key in ("generated events", "received results", "events counted in windows"):
+        out[key] = int(re.search(key + r" (\d+)", r.stdout).group(1))
+    return out
+
+
+def expected(events, sources, period_us=10):
+    views = sum(1 for v in range(events) if (v % 100000) % 3 == 0)
+    windows = (events * period_us + 10_000_000 - 1) // 10_000_000
+    return {"generated events": events * sources, "events counted in windows": views * sources, "received results": windows * 100}
+
+
+@pytest.mark.parametrize("app,n,m", [("ysb_kf", 1, 1), ("ysb_kf", 2, 3), ("ysb_wmr", 2, 2), ("ysb_wmr", 1, 3)])
+def test_ysb_cpu(app, n, m):
+    got = run_app(app, ["-e", 2_500_000, "-p", 10, "-n", n, "-m", m])
+    assert got == expected(2_500_000, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,batch", [(1, 1, 4096), (2, 2, 10000)])
+def test_ysb_gpu(n, m, batch):
+    got = run_app("ysb_gpu", ["-e", 2_500_000, "-p", 10, "-n", n, "-m", m, "-b", batch], hip=True)
+    assert got == expected(2_500_000, n)

@@ -70,5 +70,38 @@ def build_cpp(src, out, hip=False, extra=()):
     return out
 
 
+REPO = os.path.dirname(ROOT)
+
+# (source, binary, hip?) of every native program in the tree: regression programs and applications
+PROGRAMS = [
+    ("tests/cpp/smoke_basic_ops.cpp", "tests/cpp/bin/smoke_basic_ops", False),
+    ("tests/cpp/test_mp_windows.cpp", "tests/cpp/bin/test_mp_windows", False),
+    ("tests/cpp/test_graphs.cpp", "tests/cpp/bin/test_graphs", False),
+    ("tests/cpp/test_runtime.cpp", "tests/cpp/bin/test_runtime", False),
+    ("tests/cpp/test_mp_windows_gpu.hip", "tests/cpp/bin/test_mp_windows_gpu", True),
+    ("tests/cpp/test_gpu_keyed.hip", "tests/cpp/bin/test_gpu_keyed", True),
+    ("apps/ysb/ysb_kf.cpp", "apps/bin/ysb_kf", False),
+    ("apps/ysb/ysb_wmr.cpp", "apps/bin/ysb_wmr", False),
+    ("apps/ysb/ysb_gpu.hip", "apps/bin/ysb_gpu", True),
+    ("apps/bench/bench_ops_gpu.hip", "apps/bin/bench_ops_gpu", True),
+]
+
+
+def build_programs(verbose=True):
+    """Compile every native program that exists in the tree (stale ones only)."""
+    built = []
+    for src, out, hip in PROGRAMS:
+        s, o = os.path.join(REPO, src), os.path.join(REPO, out)
+        if not os.path.exists(s):
+            continue
+        extra = ["-I" + os.path.dirname(s)]
+        if verbose:
+            print("[windflow_amd.build] program", src, flush=True)
+        built.append(build_cpp(s, o, hip=hip, extra=extra))
+    return built
+
+
 if __name__ == "__main__":
     build_extension(force="--force" in sys.argv)
+    if "--all" in sys.argv:
+        build_programs()

@@ -399,10 +399,15 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         } else if (direct) {
             for (size_t i = 0; i < n; i++) g.connect_queue(prev[i].node, prev[i].port, s.replicas[i]);
         } else {
-            // heads of the new threads: [ordering ->] replica
+            // heads of the new threads: [ordering ->] replica.  Ordering nodes merge individual tuples: a
+            // shuffle of batches cannot be made deterministic (batches of different lanes overlap in time)
+            const bool batch_edge = !s.internal && tail_kind_ != EDGE_TUPLE;
+            if (batch_edge && mode == Mode::DETERMINISTIC && prev.size() > 1)
+                fatal_error("DETERMINISTIC mode: operator " + op.getName() + " would shuffle batches coming from " + std::to_string(prev.size()) +
+                            " lanes; give it the parallelism of its producer or run the PipeGraph in DEFAULT mode");
             std::vector<rt::Node*> heads(n);
             for (size_t i = 0; i < n; i++) {
-                rt::Node* ord = s.make_ordering ? s.make_ordering(mode) : nullptr;
+                rt::Node* ord = (s.make_ordering && !batch_edge) ? s.make_ordering(mode) : nullptr;
                 if (ord != nullptr) {
                     g.adopt(ord);
                     g.connect_fused(ord, ord->add_out_port(), s.replicas[i]);
