@@ -1,0 +1,335 @@
+// Unit tests of the runtime substrate and of the window building blocks (the
+// reference has none: SURVEY.md §4 "no unit-test framework"; §7 asks for SPSC /
+// graph / FlatFAT / ordering tests of our own).  Also built with
+// -fsanitize=thread by tests/test_cpu_runtime.py::test_runtime_tsan.
+//
+//   test_runtime            run every case, exit 0 iff all pass
+//   test_runtime illegal N  run illegal-topology case N (must die with a WindFlow Error)
+#include <atomic>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <optional>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include <wf/windflow.hpp>
+
+using namespace wf;
+using namespace std;
+
+static int failures = 0;
+#define CHECK(cond)                                                                         \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            cerr << "CHECK failed at " << __FILE__ << ":" << __LINE__ << ": " #cond << endl; \
+            failures++;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+// ---- SPSC ring ---------------------------------------------------------------------------------
+static void test_spsc() {
+    rt::SPSCQueue q(8);
+    CHECK(q.capacity() == 8);
+    void* out = nullptr;
+    CHECK(!q.try_pop(out));
+    for (uintptr_t i = 1; i <= 8; i++) CHECK(q.try_push(reinterpret_cast<void*>(i)));
+    CHECK(!q.try_push(reinterpret_cast<void*>(9)));  // full
+    CHECK(q.size_approx() == 8);
+    void* bulk[5];
+    CHECK(q.pop_bulk(bulk, 5) == 5);
+    for (uintptr_t i = 0; i < 5; i++) CHECK(bulk[i] == reinterpret_cast<void*>(i + 1));
+    CHECK(q.try_pop(out) && out == reinterpret_cast<void*>(6));
+    // two threads, 2M items through a ring of 64 slots: FIFO and nothing lost
+    rt::SPSCQueue ring(64);
+    const uintptr_t N = 2000000;
+    atomic<bool> ok{true};
+    thread cons([&] {
+        uintptr_t expect = 1;
+        void* items[16];
+        while (expect <= N) {
+            const size_t n = ring.pop_bulk(items, 16);
+            for (size_t i = 0; i < n; i++)
+                if (items[i] != reinterpret_cast<void*>(expect++)) ok = false;
+            if (n == 0) this_thread::yield();
+        }
+    });
+    for (uintptr_t i = 1; i <= N; i++)
+        while (!ring.try_push(reinterpret_cast<void*>(i))) this_thread::yield();
+    cons.join();
+    CHECK(ok.load());
+}
+
+// ---- graph: fan-out / fan-in, EOS propagation, back-pressure with tiny rings --------------------
+struct Producer : rt::Node {
+    long n, sent = 0;
+    explicit Producer(long n_) : n(n_) {}
+    bool is_source() const override { return true; }
+    bool generate() override {
+        emit_to(new long(sent), (size_t)(sent % (long)num_out()));
+        return ++sent < n;
+    }
+};
+struct Adder : rt::Node {
+    long add;
+    explicit Adder(long a) : add(a) {}
+    void svc(void* m, int) override {
+        long* v = static_cast<long*>(m);
+        *v += add;
+        emit(v);
+    }
+};
+struct Collector : rt::Node {
+    atomic<long>* sum;
+    atomic<long>* cnt;
+    atomic<int>* eos_seen;
+    Collector(atomic<long>* s, atomic<long>* c, atomic<int>* e) : sum(s), cnt(c), eos_seen(e) {}
+    void svc(void* m, int) override {
+        long* v = static_cast<long*>(m);
+        *sum += *v;
+        (*cnt)++;
+        delete v;
+    }
+    void eosnotify(int) override { (*eos_seen)++; }
+};
+static void test_graph() {
+    rt::RuntimeConfig cfg;
+    cfg.queue_capacity = 4;  // forces the producer to block on full rings all the time
+    rt::Graph g(cfg);
+    atomic<long> sum{0}, cnt{0};
+    atomic<int> eos{0};
+    const long N = 200000;
+    auto* p = g.adopt(new Producer(N));
+    auto* c = g.adopt(new Collector(&sum, &cnt, &eos));
+    for (int i = 0; i < 3; i++) {
+        auto* a = g.adopt(new Adder(1));
+        auto* b = g.adopt(new Adder(10));  // fused behind a: same thread
+        g.connect_queue(p, p->add_out_port(), a);
+        g.connect_fused(a, a->add_out_port(), b);
+        g.connect_queue(b, b->add_out_port(), c);
+    }
+    CHECK(g.num_threads() == 5);  // producer, 3 workers (adder pairs), collector
+    g.run();
+    g.wait();
+    CHECK(cnt == N);
+    CHECK(sum == N * (N - 1) / 2 + 11 * N);
+    CHECK(eos == 3);  // one notification per input channel
+}
+
+// ---- tuples with string keys -----------------------------------------------------------------------
+struct skey_t {
+    string key;
+    uint64_t id = 0, ts = 0;
+    long value = 0;
+    tuple<string, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    void setControlFields(string k, uint64_t i, uint64_t t) {
+        key = std::move(k);
+        id = i;
+        ts = t;
+    }
+};
+static void test_string_keys() {
+    // Source -> Accumulator (keyed) -> Key_Farm CB windows -> Sink, keys are strings (reference: test_mp_*_string.cpp)
+    const vector<string> names = {"alpha", "beta", "gamma", "delta", "epsilon"};
+    const long per_key = 3000;
+    for (int run = 0; run < 2; run++) {
+        PipeGraph graph("string_keys", Mode::DETERMINISTIC);  // count-based windows need DETERMINISTIC mode
+        long sent = 0;
+        vector<uint64_t> ids(names.size(), 0);
+        Source src = Source_Builder([=](skey_t& t) mutable {
+                         const size_t k = (size_t)sent % names.size();
+                         t.setControlFields(names[k], ids[k]++, (uint64_t)sent);
+                         t.value = 1;
+                         sent++;
+                         return sent < per_key * (long)names.size();
+                     }).withParallelism(1).build();
+        MultiPipe& mp = graph.add_source(src);
+        Accumulator acc = Accumulator_Builder([](const skey_t& t, skey_t& a) { a.value += t.value; }).withParallelism(run == 0 ? 1 : 3).build();
+        mp.add(acc);  // emits the running count per key: 1, 2, 3 ...
+        Key_Farm kf = KeyFarm_Builder([](uint64_t, const skey_t& t, skey_t& out) { out.value += t.value; })
+                          .withCBWindows(10, 10).withParallelism(2).build();
+        mp.add(kf);
+        atomic<long> total{0}, windows{0};
+        Sink sink = Sink_Builder([&](optional<skey_t>& r) {
+                        if (r) {
+                            total += r->value;
+                            windows++;
+                        }
+                    }).withParallelism(1).build();
+        mp.add_sink(sink);
+        graph.run();
+        CHECK(windows == (long)names.size() * per_key / 10);
+        CHECK(total == (long)names.size() * per_key * (per_key + 1) / 2);
+    }
+}
+
+// ---- FlatFAT against a brute-force fold (non-commutative combine) -------------------------------------
+static void test_flatfat() {
+    struct S {
+        string s;
+        size_t key = 0;
+        uint64_t id = 0, ts = 0;
+        S() = default;
+        explicit S(string v) : s(std::move(v)) {}
+        tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+        void setControlFields(size_t k, uint64_t i, uint64_t t) {
+            key = k;
+            id = i;
+            ts = t;
+        }
+    };
+    using comb_t = std::function<void(const S&, const S&, S&)>;
+    const comb_t concat = [](const S& a, const S& b, S& out) { out.s = a.s + b.s; };
+    FlatFAT<S, comb_t> fat(concat, 10);
+    CHECK(fat.capacity() == 16);
+    string model;
+    S r;
+    CHECK(!fat.getResult(r));
+    unsigned seed = 7;
+    for (int step = 0; step < 5000; step++) {
+        seed = seed * 1103515245u + 12345u;
+        const bool can_insert = fat.size() < fat.capacity();
+        if (can_insert && ((seed >> 16) % 3 != 0 || fat.is_Empty())) {
+            const char c = (char)('a' + (seed >> 8) % 26);
+            fat.insert(S{string(1, c)});
+            model.push_back(c);
+        } else if (!fat.is_Empty()) {
+            fat.remove();
+            model.erase(model.begin());
+        }
+        const bool has = fat.getResult(r);
+        CHECK(has == !model.empty());
+        if (has && r.s != model) {
+            CHECK(r.s == model);
+            break;
+        }
+    }
+    // bulk insert keeps the order too
+    FlatFAT<S, comb_t> fat2(concat, 32);
+    vector<S> many;
+    string exp;
+    for (int i = 0; i < 20; i++) {
+        many.push_back(S{string(1, (char)('A' + i))});
+        exp.push_back((char)('A' + i));
+    }
+    fat2.insert(many);
+    CHECK(fat2.getResult(r) && r.s == exp);
+    fat2.remove(5);
+    CHECK(fat2.getResult(r) && r.s == exp.substr(5));
+}
+
+// ---- statistics + DOT dump ---------------------------------------------------------------------------
+struct rec_t {
+    size_t key = 0;
+    uint64_t id = 0, ts = 0;
+    long value = 0;
+    tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    void setControlFields(size_t k, uint64_t i, uint64_t t) {
+        key = k;
+        id = i;
+        ts = t;
+    }
+};
+static void test_stats_and_dot() {
+    PipeGraph graph("stats", Mode::DEFAULT);
+    long v = 0;
+    Source src = Source_Builder([=](rec_t& t) mutable {
+                     t.setControlFields((size_t)v % 3, (uint64_t)v / 3, (uint64_t)v);
+                     t.value = v++;
+                     return v < 9000;
+                 }).withName("numbers").withParallelism(1).build();
+    MultiPipe& mp = graph.add_source(src);
+    Filter f = Filter_Builder([](rec_t& t) { return t.value % 3 == 0; }).withName("thirds").withParallelism(2).build();
+    mp.add(f);
+    Map m = Map_Builder([](rec_t& t) { t.value *= 2; }).withName("double").withParallelism(2).build();
+    mp.chain(m);
+    atomic<long> n{0};
+    Sink s = Sink_Builder([&](optional<rec_t>& r) {
+                 if (r) n++;
+             }).withName("count").withParallelism(1).build();
+    mp.add_sink(s);
+    const string dot = graph.get_DOTGraph();
+    for (const char* name : {"numbers", "thirds", "double", "count"}) CHECK(dot.find(name) != string::npos);
+    CHECK(dot.find("digraph") != string::npos);
+    CHECK(graph.get_ListOperators().size() == 4);
+    CHECK(graph.getNumThreads() == 1 + 2 + 1);  // the Map is chained to the Filter
+    graph.run();
+    CHECK(n == 3000);
+    long in_filter = 0, out_filter = 0, in_map = 0;
+    for (auto& r : f.get_StatsRecords()) {
+        in_filter += (long)r.inputs_received;
+        out_filter += (long)r.outputs_sent;
+    }
+    for (auto& r : m.get_StatsRecords()) in_map += (long)r.inputs_received;
+    CHECK(f.get_StatsRecords().size() == 2);
+    CHECK(in_filter == 9000);
+    CHECK(out_filter == 3000);
+    CHECK(in_map == 3000);
+}
+
+// ---- illegal topologies must be refused -----------------------------------------------
+static int illegal(int which) {
+    PipeGraph graph("illegal", Mode::DEFAULT);
+    auto gen = [](rec_t& t) {
+        t.value = 1;
+        return false;
+    };
+    Source src = Source_Builder(gen).withParallelism(1).build();
+    Source src2 = Source_Builder(gen).withParallelism(1).build();
+    Map m = Map_Builder([](rec_t& t) { t.value++; }).withParallelism(1).build();
+    Sink s = Sink_Builder([](optional<rec_t>&) {}).withParallelism(1).build();
+    MultiPipe& mp = graph.add_source(src);
+    switch (which) {
+        case 0:  // operator used twice
+            mp.add(m);
+            mp.add(m);
+            break;
+        case 1:  // operator after a sink
+            mp.add_sink(s);
+            mp.add(m);
+            break;
+        case 2:  // select on a MultiPipe that was not split
+            mp.select(0);
+            break;
+        case 3:  // adding to a MultiPipe that has been split
+            mp.split([](const rec_t&) -> size_t { return 0; }, 2);
+            mp.add(m);
+            break;
+        case 4:  // running a graph with an unterminated MultiPipe
+            mp.add(m);
+            graph.run();
+            break;
+        case 5: {  // adding to a MultiPipe that has been merged
+            MultiPipe& other = graph.add_source(src2);
+            mp.merge(other);
+            mp.add(m);
+            break;
+        }
+        case 6: {  // type mismatch between consecutive operators
+            Map ms = Map_Builder([](skey_t& t) { t.value++; }).withParallelism(1).build();
+            mp.add(ms);
+            break;
+        }
+        case 7:  // Key_FFAT on a tumbling window is refused like in the reference (sliding windows only)... CB window of length zero
+        {
+            Key_Farm kf = KeyFarm_Builder([](uint64_t, const rec_t& t, rec_t& out) { out.value += t.value; }).withCBWindows(0, 1).build();
+            mp.add(kf);
+            break;
+        }
+        default: return 0;
+    }
+    return 0;  // reaching this point means the library accepted the topology
+}
+
+int main(int argc, char** argv) {
+    if (argc == 3 && strcmp(argv[1], "illegal") == 0) return illegal(atoi(argv[2]));
+    test_spsc();
+    test_graph();
+    test_string_keys();
+    test_flatfat();
+    test_stats_and_dot();
+    cout << (failures == 0 ? "ALL OK" : "FAILED") << endl;
+    return failures == 0 ? 0 : 1;
+}

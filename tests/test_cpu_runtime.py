@@ -61,3 +61,37 @@ def test_mp_windows_tumbling_and_dense_sliding(win, slide):
     for op in ["wf", "kf"]:
         out = run_cpp("test_mp_windows", ["-t", op, "-m", "cb", "-r", 2, "-l", 600, "-k", 3, "-w", win, "-s", slide])
         assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+GRAPH_SCENARIOS = ["merge_1", "merge_2", "merge_3", "merge_4", "split_1", "split_2", "split_3", "split_4", "split_5",
+                   "graph_1", "graph_2", "graph_3", "graph_4", "graph_5", "graph_6", "graph_7", "graph_8", "graph_9"]
+
+
+@pytest.mark.parametrize("scenario", GRAPH_SCENARIOS)
+def test_split_merge_graphs(scenario):
+    """Split / merge / DAG topologies under random parallelism against sequential oracles (reference: merge_test,
+    split_test, graph_test)."""
+    out = run_cpp("test_graphs", ["-t", scenario, "-r", 3, "-n", 12000])
+    assert out.count("  OK") == 3 and "FAILED" not in out
+
+
+def test_runtime_units():
+    """SPSC ring, graph EOS/back-pressure, string keys, FlatFAT vs brute force, statistics + DOT."""
+    assert "ALL OK" in run_cpp("test_runtime")
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_illegal_topologies_are_refused(case):
+    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_runtime.cpp"), os.path.join(BIN, "test_runtime"))
+    r = subprocess.run([exe, "illegal", str(case)], capture_output=True, text=True, timeout=60, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 1 and "WindFlow Error" in r.stderr
+
+
+def test_runtime_tsan():
+    """The runtime unit tests under ThreadSanitizer (host code only)."""
+    src = os.path.join(HERE, "cpp", "test_runtime.cpp")
+    exe = os.path.join(BIN, "test_runtime_tsan")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + wfbuild.INCLUDE, src, "-o", exe, "-pthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
