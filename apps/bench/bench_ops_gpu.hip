@@ -1,0 +1,186 @@
+// Throughput benchmarks of the batched GPU operators, mirroring the reference's
+// operator studies (/root/reference/src/GPU_Tests/new_tests/benchmarks/
+// gpu_map_stateless.cpp, gpu_filter_stateless.cpp, gpu_map_stateful.cpp,
+// gpu_filter_stateful.cpp and their run_tests.py sweeps over -s -k -b -n; the
+// published numbers are in BASELINE.md: 147.5 M tuples/s stateless map,
+// 118.6 M tuples/s stateful map) but built from the library's operators:
+//
+//   Batch_Source x S  ->  <operator> x N  ->  Batch_Sink x N
+//
+//   -o map_stateless     in-place map doing a lookup in a device hash table
+//   -o filter_stateless  predicate + on-device stable compaction
+//   -o map_stateful      keyed map: per-key window of the last 1000 values, incremental average (8 KB of state per key)
+//   -o filter_stateful   keyed filter on the same state: keeps tuples above the running average
+//   -o keyby             device KeyBy only (scattering study): S lanes re-partitioned into N
+//
+//   bench_ops_gpu -o <op> [-s sources] [-n operator replicas] [-k keys] [-b batch length] [-t seconds]
+//
+// prints one line:  <op> sources=S replicas=N keys=K batch=B : X tuples/s (Y results/s), elapsed Z s
+#include <unistd.h>
+
+#include <atomic>
+#include <iostream>
+#include <string>
+
+#include <wf/windflow_gpu.hpp>
+
+#include "../../windflow_amd/csrc/bench_common.hpp"
+
+using namespace wf;
+using wfbench::tuple_t;
+
+// ---- stateless functors ---------------------------------------------------------------------------
+struct TableEntry {
+    unsigned long long key, value;
+};
+struct LookupMap {
+    const TableEntry* table;
+    uint32_t mask;
+    __host__ __device__ void operator()(tuple_t& t) const {
+        uint32_t h = (uint32_t)(t.key * 0x9E3779B97F4A7C15ull >> 40) & mask;
+        for (uint32_t probes = 0; probes <= mask; probes++) {
+            if (table[h].key == t.key) {
+                t.id = table[h].value;
+                return;
+            }
+            if (table[h].key == ~0ull) break;
+            h = (h + 1) & mask;
+        }
+        t.id = 0;
+    }
+};
+struct HalfFilter {
+    __host__ __device__ bool operator()(const tuple_t& t) const { return ((uint64_t)t.value & 1) == 0; }
+};
+
+// ---- stateful functors: the reference's Window_State (gpu_map_stateful.cpp:371-403) ------------------
+struct WindowState {
+    static constexpr uint32_t CAP = 1000;
+    double values[CAP];
+    double sum;
+    uint32_t first, last, count, pad;
+    __host__ __device__ double push(double v) {
+        if (count == CAP) {
+            sum -= values[first];
+            first = first + 1 == CAP ? 0 : first + 1;
+        } else {
+            count++;
+        }
+        values[last] = v;
+        last = last + 1 == CAP ? 0 : last + 1;
+        sum += v;
+        return sum / count;
+    }
+};
+struct RunningAverageMap {
+    __host__ __device__ void operator()(tuple_t& t, char* state, size_t) const { t.aux = reinterpret_cast<WindowState*>(state)->push(t.value); }
+};
+struct AboveAverageFilter {
+    __host__ __device__ void operator()(const tuple_t& t, bool& keep, char* state, size_t) const {
+        keep = t.value >= reinterpret_cast<WindowState*>(state)->push(t.value);
+    }
+};
+
+// endless generator: keys round-robin inside a per-source key range, stops after `seconds`
+struct TimedGenerator {
+    size_t n_keys, n_sources;
+    uint64_t stop_at_us;
+    uint64_t seq = 0;
+    std::atomic<uint64_t>* generated;
+    bool operator()(tuple_t* buf, size_t cap, size_t& n, RuntimeContext& ctx) {
+        const uint64_t src = ctx.getReplicaIndex();
+        uint64_t s = seq;
+        for (size_t i = 0; i < cap; i++, s++) {
+            buf[i].key = (s % n_keys) * n_sources + src;
+            buf[i].id = s / n_keys;
+            buf[i].ts = s;
+            buf[i].value = (double)((s * 2654435761ull >> 7) & 1023);
+            buf[i].aux = 0.0;
+        }
+        seq = s;
+        n = cap;
+        generated->fetch_add(cap, std::memory_order_relaxed);
+        return current_time_usecs() < stop_at_us;
+    }
+};
+
+int main(int argc, char** argv) {
+    std::string op = "map_stateless";
+    size_t sources = 4, replicas = 0, keys = 1 << 14, batch = 1 << 17;
+    double seconds = 3.0;
+    int c;
+    while ((c = getopt(argc, argv, "o:s:n:k:b:t:")) != -1) {
+        switch (c) {
+            case 'o': op = optarg; break;
+            case 's': sources = std::strtoull(optarg, nullptr, 10); break;
+            case 'n': replicas = std::strtoull(optarg, nullptr, 10); break;
+            case 'k': keys = std::strtoull(optarg, nullptr, 10); break;
+            case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
+            case 't': seconds = std::atof(optarg); break;
+            default:
+                std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|filter_stateful|keyby [-s sources] [-n replicas] "
+                          << "[-k keys] [-b batch] [-t seconds]" << std::endl;
+                return 0;
+        }
+    }
+    if (replicas == 0) replicas = sources;
+    if (gpu::device_count() < 1) {
+        std::cerr << "bench_ops_gpu needs a GPU" << std::endl;
+        return 3;
+    }
+    const size_t keys_per_source = std::max<size_t>(1, keys / sources);
+    std::atomic<uint64_t> generated{0}, results{0};
+
+    // lookup table for the stateless map
+    gpu::DeviceBuffer<TableEntry> table;
+    uint32_t mask = 0;
+    if (op == "map_stateless") {
+        size_t cap = 2;
+        while (cap < 2 * keys_per_source * sources) cap <<= 1;
+        mask = (uint32_t)(cap - 1);
+        std::vector<TableEntry> host(cap, TableEntry{~0ull, 0});
+        for (size_t k = 0; k < keys_per_source * sources; k++) {
+            uint32_t h = (uint32_t)(k * 0x9E3779B97F4A7C15ull >> 40) & mask;
+            while (host[h].key != ~0ull) h = (h + 1) & mask;
+            host[h] = TableEntry{k, k * 7 + 1};
+        }
+        table.resize(cap);
+        WF_HIP_CHECK(hipMemcpy(table.data(), host.data(), cap * sizeof(TableEntry), hipMemcpyHostToDevice));
+    }
+
+    PipeGraph graph("bench_" + op, Mode::DEFAULT);
+    const uint64_t t0 = current_time_usecs();
+    TimedGenerator gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), 0, &generated};
+    auto src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).build_unique();
+    MultiPipe& mp = graph.add_source(*src);
+    std::unique_ptr<Basic_Operator> oper;
+    const bool disjoint = (replicas == sources);  // lane i carries exactly the keys of replica i
+    if (op == "map_stateless") {
+        oper = MapGPU_Builder(LookupMap{table.data(), mask}).withName(op).withParallelism(replicas).build_unique();
+    } else if (op == "filter_stateless") {
+        oper = FilterGPU_Builder(HalfFilter()).withName(op).withParallelism(replicas).build_unique();
+    } else if (op == "map_stateful" || op == "keyby") {
+        auto b = MapGPU_Builder(RunningAverageMap()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))
+                     .withMaxKeys(keys_per_source * sources / (disjoint ? sources : 1) + 1024);
+        if (disjoint && op != "keyby") b.withKeyDisjointLanes();
+        oper = b.build_unique();
+    } else if (op == "filter_stateful") {
+        auto b = FilterGPU_Builder(AboveAverageFilter()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))
+                     .withMaxKeys(keys_per_source * sources / (disjoint ? sources : 1) + 1024);
+        if (disjoint) b.withKeyDisjointLanes();
+        oper = b.build_unique();
+    } else {
+        std::cerr << "unknown operator " << op << std::endl;
+        return 2;
+    }
+    mp.add(*oper);
+    auto sink = BatchSink_Builder([&results](const tuple_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
+                    .withName("sink").withParallelism(replicas).build_unique();
+    mp.chain_sink(*sink);
+    graph.run();
+    const double elapsed = (current_time_usecs() - t0) / 1e6;
+    std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " batch=" << batch << " : "
+              << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed << " results/s), elapsed " << elapsed
+              << " s" << std::endl;
+    return 0;
+}

@@ -63,19 +63,69 @@ struct FFATCounters {
     uint32_t table_full;       // tuples whose key could not be inserted
 };
 
+// where fired windows go.  GlobalEmit: one returning atomic per result (fine when a thread fires a
+// handful of windows per batch).  WaveEmit: lane 0 of a wave parks results in LDS and the whole wave
+// flushes them with ONE atomic per chunk (a returning global atomic costs microseconds: it must not
+// sit on the sequential path of a long run).
 template <typename R>
-__device__ __forceinline__ void ffat_emit(R* out, uint32_t* out_count, const FFATGeometry& g, FFATCounters* ctr, const R& r) {
-    const uint32_t pos = atomicAdd(out_count, 1u);
-    if (pos < g.out_cap)
-        out[pos] = r;
-    else
-        atomicAdd(&ctr->overflow, 1u);
-}
+struct GlobalEmit {
+    R* out;
+    uint32_t* out_count;
+    uint32_t out_cap;
+    FFATCounters* ctr;
+    __device__ __forceinline__ void operator()(const R& r) {
+        const uint32_t pos = atomicAdd(out_count, 1u);
+        if (pos < out_cap)
+            out[pos] = r;
+        else
+            atomicAdd(&ctr->overflow, 1u);
+    }
+};
+
+template <typename R>
+struct WaveEmit {
+    R* buf;  // LDS, WAVE entries
+    uint32_t n;
+    R* out;
+    uint32_t* out_count;
+    uint32_t out_cap;
+    FFATCounters* ctr;
+    // called by lane 0 only
+    __device__ __forceinline__ void operator()(const R& r) {
+        if (n == (uint32_t)WAVE) {  // rare: more than 64 windows fired inside one chunk (long silent gaps)
+            const uint32_t base = atomicAdd(out_count, n);
+            for (uint32_t k = 0; k < n; k++) {
+                if (base + k < out_cap)
+                    out[base + k] = buf[k];
+                else
+                    atomicAdd(&ctr->overflow, 1u);
+            }
+            n = 0;
+        }
+        buf[n++] = r;
+    }
+    // called by the whole wave after lane 0 is done with a chunk
+    __device__ __forceinline__ void flush_wave() {
+        const uint32_t cnt = (uint32_t)__shfl((int)n, 0, WAVE);
+        if (cnt == 0) return;
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(out_count, cnt);
+        base = (uint32_t)__shfl((int)base, 0, WAVE);
+        const uint32_t l = (uint32_t)lane_id();
+        if (l < cnt) {
+            if (base + l < out_cap)
+                out[base + l] = buf[l];
+            else
+                atomicAdd(&ctr->overflow, 1u);
+        }
+        n = 0;
+    }
+};
 
 // a pane is complete: insert it in the key's tree and fire the window it closes (if any)
-template <typename R, typename C, typename K>
+template <typename R, typename C, typename K, typename E>
 __device__ __forceinline__ void ffat_complete_pane(FFATKeyState<R>& st, R* tree, const FFATGeometry& g, const K& key, const R& pane, const C& comb,
-                                                   R* out, uint32_t* out_count, FFATCounters* ctr) {
+                                                   E& emit) {
     fat_insert(tree, g.tree_cap, (uint32_t)(st.panes & (g.tree_cap - 1)), pane, comb);
     st.panes++;
     if (st.panes >= g.win_panes && (st.panes - g.win_panes) % g.slide_panes == 0) {
@@ -83,17 +133,127 @@ __device__ __forceinline__ void ffat_complete_pane(FFATKeyState<R>& st, R* tree,
         fat_query_circular(tree, g.tree_cap, (uint32_t)((st.panes - g.win_panes) & (g.tree_cap - 1)), g.win_panes, res, comb);
         res.setControlFields(key, st.next_lwid, cf_ts(res));
         st.next_lwid++;
-        ffat_emit(out, out_count, g, ctr, res);
+        emit(res);
     }
 }
 
 constexpr int FFAT_PREFETCH = 4;
+// runs of at least this many tuples are left to the wave-per-run kernel
+constexpr uint32_t FFAT_LONG_RUN = 32;
 
-// one thread per run of equal slots in the sorted (slot, index) arrays
+// `lifted` is the aggregate of `len` consecutive tuples of a key that all belong to the same pane
+// (CB) / quantum (TB): fold it into the open pane / quantum and complete what it closes.  With
+// len = 1 this is the per-tuple step of the reference engine (win_seqffat.hpp CB :330-419, TB :422-513).
+template <typename R, typename C, typename E>
+__device__ __forceinline__ void ffat_fold(FFATKeyState<R>& st, R* tree, R* acc, uint8_t* used, const FFATGeometry& g, const R& lifted, uint32_t len,
+                                          const C& comb, E& emit, FFATCounters* ctr) {
+    const auto key = cf_key(lifted);
+    const uint64_t ts = cf_ts(lifted);  // greatest timestamp folded in `lifted`
+    st.seen = 1;
+    if (!g.is_tb) {
+        if (st.pcount == 0) {
+            st.partial = lifted;
+        } else {
+            R tmp;
+            fat_combine(comb, st.partial, lifted, tmp);
+            st.partial = tmp;
+        }
+        st.pcount += len;
+        if (st.pcount == g.pane_len) {
+            ffat_complete_pane(st, tree, g, key, st.partial, comb, emit);
+            st.pcount = 0;
+        }
+        return;
+    }
+    const uint64_t q = ts / g.pane_len;
+    if (q < st.last_quantum) {
+        atomicAdd(&ctr->dropped, len);
+        return;
+    }
+    // quanta whose last instant + delay is older than ts are complete
+    uint64_t done_upto = (ts > g.delay) ? (ts - g.delay) / g.pane_len : 0;  // quanta < done_upto are complete
+    // the ring of open quanta must be able to hold q
+    if (q >= done_upto + g.acc_cap) done_upto = q - g.acc_cap + 1;
+    if (done_upto > st.last_quantum) {
+        auto complete_until = [&](uint64_t upto) {
+            while (st.last_quantum < upto) {
+                const uint32_t a = (uint32_t)(st.last_quantum & (g.acc_cap - 1));
+                R pane{};
+                if (used[a]) {
+                    pane = acc[a];
+                    used[a] = 0;
+                }
+                pane.setControlFields(key, st.last_quantum, (st.last_quantum + 1) * g.pane_len - 1);
+                ffat_complete_pane(st, tree, g, key, pane, comb, emit);
+                st.last_quantum++;
+            }
+        };
+        // A time jump much longer than the tree: flush the quanta that can hold data
+        // (and the windows containing them), then fast-forward over the stretch in
+        // which every window is empty instead of materialising each of them.
+        const uint64_t keep = (uint64_t)g.tree_cap + g.acc_cap;
+        if (g.skip_gaps && done_upto - st.last_quantum > 4 * keep) {
+            complete_until(st.last_quantum + keep);
+            const uint64_t skip = done_upto - keep - st.last_quantum;
+            const uint64_t panes_after = st.panes + skip;
+            const uint64_t fired_after = panes_after >= g.win_panes ? (panes_after - g.win_panes) / g.slide_panes + 1 : 0;
+            if (fired_after > st.next_lwid) {
+                atomicAdd(&ctr->skipped_windows, (uint32_t)(fired_after - st.next_lwid));
+                st.next_lwid = fired_after;
+            }
+            st.panes = panes_after;
+            st.last_quantum += skip;
+        }
+        complete_until(done_upto);
+    }
+    const uint32_t a = (uint32_t)(q & (g.acc_cap - 1));
+    if (used[a]) {
+        R tmp;
+        fat_combine(comb, acc[a], lifted, tmp);
+        acc[a] = tmp;
+    } else {
+        acc[a] = lifted;
+        used[a] = 1;
+    }
+    if (q + 1 > st.max_quantum) st.max_quantum = q + 1;
+}
+
+template <typename T, typename R, typename L>
+__device__ __forceinline__ R ffat_lift(const T& t, const L& lift) {
+    R lifted{};
+    lifted.setControlFields(cf_key(t), 0, cf_ts(t));
+    lift(t, lifted);
+    return lifted;
+}
+
+template <typename T, typename R, typename L, typename C, typename E>
+__device__ __forceinline__ void ffat_process_tuple(FFATKeyState<R>& st, R* tree, R* acc, uint8_t* used, const FFATGeometry& g, const T& t,
+                                                   const L& lift, const C& comb, E& emit, FFATCounters* ctr) {
+    ffat_fold(st, tree, acc, used, g, ffat_lift<T, R, L>(t, lift), 1u, comb, emit, ctr);
+}
+
+// the value of `v` held by lane (lane - d); any trivially copyable struct made of 32-bit words
+template <typename X>
+__device__ __forceinline__ X wave_shfl_up(const X& v, int d) {
+    static_assert(sizeof(X) % 4 == 0, "wave shuffles move 32-bit words");
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(X) / 4; k++) w[k] = __shfl_up(w[k], d, WAVE);
+    X o;
+    __builtin_memcpy(&o, w, sizeof(X));
+    return o;
+}
+
+// Short runs: one thread per run of equal slots in the sorted (slot, index) arrays.  Heads of
+// runs of FFAT_LONG_RUN tuples or more are only recorded in `long_heads` for the wave-per-run
+// kernel below (streams with few keys would otherwise serialise thousands of dependent random
+// loads in one thread).
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
-                       R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, L lift, C comb) {
+                       R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
+                       uint32_t* n_long, L lift, C comb) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
@@ -102,10 +262,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             atomicAdd(&ctr->table_full, 1u);
             continue;
         }
+        if (i + FFAT_LONG_RUN - 1 < n && sslot[i + FFAT_LONG_RUN - 1] == slot) {
+            long_heads[atomicAdd(n_long, 1u)] = i;
+            continue;
+        }
         FFATKeyState<R> st = states[slot];
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         R* acc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
         uint8_t* used = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
+        GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
         // software prefetch: the tuples of a run are gathered FFAT_PREFETCH at a time so that
         // their (dependent, random) loads are in flight together
         bool run_open = true;
@@ -120,86 +285,171 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             }
 #pragma unroll
             for (int u = 0; u < FFAT_PREFETCH; u++) {
-            if (!ok[u]) {
-                run_open = false;
-                break;
+                if (!ok[u]) {
+                    run_open = false;
+                    break;
+                }
+                ffat_process_tuple(st, tree, acc, used, g, pre[u], lift, comb, emit, ctr);
             }
-            const T& t = pre[u];
-            const auto key = cf_key(t);
-            const uint64_t ts = cf_ts(t);
-            st.seen = 1;
-            R lifted{};
-            lifted.setControlFields(key, 0, ts);
-            lift(t, lifted);
-            if (!g.is_tb) {
-                if (st.pcount == 0) {
-                    st.partial = lifted;
-                } else {
-                    R tmp;
-                    fat_combine(comb, st.partial, lifted, tmp);
-                    st.partial = tmp;
-                }
-                st.pcount++;
-                if (st.pcount == g.pane_len) {
-                    ffat_complete_pane(st, tree, g, key, st.partial, comb, out, out_count, ctr);
-                    st.pcount = 0;
-                }
-            } else {
-                const uint64_t q = ts / g.pane_len;
-                if (q < st.last_quantum) {
-                    atomicAdd(&ctr->dropped, 1u);
-                    continue;
-                }
-                // quanta whose last instant + delay is older than ts are complete
-                uint64_t done_upto = (ts > g.delay) ? (ts - g.delay) / g.pane_len : 0;  // quanta < done_upto are complete
-                // the ring of open quanta must be able to hold q
-                if (q >= done_upto + g.acc_cap) done_upto = q - g.acc_cap + 1;
-                if (done_upto > st.last_quantum) {
-                    auto complete_until = [&](uint64_t upto) {
-                        while (st.last_quantum < upto) {
-                            const uint32_t a = (uint32_t)(st.last_quantum & (g.acc_cap - 1));
-                            R pane{};
-                            if (used[a]) {
-                                pane = acc[a];
-                                used[a] = 0;
-                            }
-                            pane.setControlFields(key, st.last_quantum, (st.last_quantum + 1) * g.pane_len - 1);
-                            ffat_complete_pane(st, tree, g, key, pane, comb, out, out_count, ctr);
-                            st.last_quantum++;
-                        }
-                    };
-                    // A time jump much longer than the tree: flush the quanta that can hold data
-                    // (and the windows containing them), then fast-forward over the stretch in
-                    // which every window is empty instead of materialising each of them.
-                    const uint64_t keep = (uint64_t)g.tree_cap + g.acc_cap;
-                    if (g.skip_gaps && done_upto - st.last_quantum > 4 * keep) {
-                        complete_until(st.last_quantum + keep);
-                        const uint64_t skip = done_upto - keep - st.last_quantum;
-                        const uint64_t panes_after = st.panes + skip;
-                        const uint64_t fired_after = panes_after >= g.win_panes ? (panes_after - g.win_panes) / g.slide_panes + 1 : 0;
-                        if (fired_after > st.next_lwid) {
-                            atomicAdd(&ctr->skipped_windows, (uint32_t)(fired_after - st.next_lwid));
-                            st.next_lwid = fired_after;
-                        }
-                        st.panes = panes_after;
-                        st.last_quantum += skip;
-                    }
-                    complete_until(done_upto);
-                }
-                const uint32_t a = (uint32_t)(q & (g.acc_cap - 1));
-                if (used[a]) {
-                    R tmp;
-                    fat_combine(comb, acc[a], lifted, tmp);
-                    acc[a] = tmp;
-                } else {
-                    acc[a] = lifted;
-                    used[a] = 1;
-                }
-                if (q + 1 > st.max_quantum) st.max_quantum = q + 1;
-            }
-        }
         }
         states[slot] = st;
+    }
+}
+
+// Long runs: one wave64 per run, exploiting the associativity of the combine.  The 64 lanes gather
+// and LIFT the next 64 tuples of the run together; lanes whose tuples fall in the same pane (CB) /
+// quantum (TB) form a segment and a segmented wave scan (6 shuffle + combine steps, order
+// preserving, so the combine needs not be commutative) leaves each segment's aggregate in its last
+// lane.  Only the per-SEGMENT step (fold into the open pane, complete panes, fire windows) is
+// sequential, in lane 0.  When it fits, the key's tree is staged in LDS for the whole run, so
+// pane inserts and window queries never wait on HBM.  Dynamic LDS per wave: 64 segment slots +
+// `lds_nodes` tree nodes.
+template <typename R>
+struct FFATSegment {
+    R agg;
+    uint32_t len;
+    uint32_t pad;
+};
+
+// LDS layout of one wave of the long-run kernel
+template <typename R>
+struct FFATLongLayout {
+    uint32_t tree_nodes;  // 0: the tree stays in global memory
+    uint32_t acc_slots;   // 0: the ring of open quanta stays in global memory
+    __host__ __device__ static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+    __host__ __device__ size_t segs_off() const { return 0; }
+    __host__ __device__ size_t res_off() const { return align16(WAVE * sizeof(FFATSegment<R>)); }
+    __host__ __device__ size_t tree_off() const { return res_off() + align16(WAVE * sizeof(R)); }
+    __host__ __device__ size_t acc_off() const { return tree_off() + align16((size_t)tree_nodes * sizeof(R)); }
+    __host__ __device__ size_t used_off() const { return acc_off() + align16((size_t)acc_slots * sizeof(R)); }
+    __host__ __device__ size_t wave_bytes() const { return used_off() + align16(acc_slots); }
+    // stage as much of the per-key state as fits `budget` bytes per wave
+    static FFATLongLayout choose(uint32_t tree_cap, uint32_t acc_cap, bool is_tb, size_t budget) {
+        FFATLongLayout l{0, 0};
+        FFATLongLayout with_acc{0, is_tb ? acc_cap : 0};
+        if (with_acc.wave_bytes() <= budget) l = with_acc;
+        FFATLongLayout with_tree{2 * tree_cap, l.acc_slots};
+        if (with_tree.wave_bytes() <= budget) l = with_tree;
+        return l;
+    }
+};
+
+template <typename T, typename R, typename L, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
+                            R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
+                            const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb) {
+    extern __shared__ __align__(16) char ffat_smem[];
+    const uint32_t n = hdr->count;
+    const uint32_t runs = *n_long;
+    const int lane = lane_id();
+    char* my = ffat_smem + (size_t)wave_id() * lay.wave_bytes();
+    FFATSegment<R>* segs = reinterpret_cast<FFATSegment<R>*>(my + lay.segs_off());
+    R* ltree = reinterpret_cast<R*>(my + lay.tree_off());
+    R* lacc = reinterpret_cast<R*>(my + lay.acc_off());
+    uint8_t* lused = reinterpret_cast<uint8_t*>(my + lay.used_off());
+    WaveEmit<R> emit{reinterpret_cast<R*>(my + lay.res_off()), 0u, out, out_count, g.out_cap, ctr};
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < runs; r += waves_total) {
+        const uint32_t head = long_heads[r];
+        const uint32_t slot = sslot[head];
+        FFATKeyState<R> st = states[slot];  // lane 0's copy is the live one
+        R* gtree = trees + (size_t)slot * 2 * g.tree_cap;
+        R* tree = gtree;
+        if (lay.tree_nodes != 0) {
+            for (uint32_t k = lane; k < 2 * g.tree_cap; k += WAVE) ltree[k] = gtree[k];
+            tree = ltree;
+        }
+        R* gacc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
+        uint8_t* gused = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
+        R* acc = gacc;
+        uint8_t* used = gused;
+        if (g.is_tb && lay.acc_slots != 0) {
+            for (uint32_t k = lane; k < g.acc_cap; k += WAVE) {
+                lacc[k] = gacc[k];
+                lused[k] = gused[k];
+            }
+            acc = lacc;
+            used = lused;
+        }
+        // software pipeline: chunk c+1 is loaded into registers before chunk c is reduced
+        uint32_t j = head + lane;
+        bool ok = (j < n) && (sslot[j] == slot);
+        T reg{};
+        if (ok) reg = data[sidx[j]];
+        while (true) {
+            const unsigned long long okmask = __ballot(ok);  // the valid lanes are a prefix: the arrays are sorted
+            const uint32_t cnt = (uint32_t)__popcll(okmask);
+            // 1. lift + segment key
+            R val{};
+            uint64_t segkey = 0;
+            const uint32_t pc0 = (uint32_t)__shfl((int)st.pcount, 0, WAVE);  // tuples already in the open pane (CB)
+            if (ok) {
+                val = ffat_lift<T, R, L>(reg, lift);
+                segkey = g.is_tb ? cf_ts(reg) / g.pane_len : ((uint64_t)pc0 + (uint64_t)lane) / g.pane_len;
+            }
+            // next chunk's loads go out now and complete while this chunk is reduced
+            T nreg{};
+            bool nok = false;
+            if (cnt == WAVE) {
+                j += WAVE;
+                nok = (j < n) && (sslot[j] == slot);
+                if (nok) nreg = data[sidx[j]];
+            }
+            // 2. segment index = number of boundaries at or before this lane
+            const uint32_t lo = (uint32_t)(segkey & 0xffffffffu), hi = (uint32_t)(segkey >> 32);
+            const uint32_t plo = (uint32_t)__shfl_up((int)lo, 1, WAVE), phi = (uint32_t)__shfl_up((int)hi, 1, WAVE);
+            const bool boundary = ok && (lane == 0 || plo != lo || phi != hi);
+            const unsigned long long bmask = __ballot(boundary);
+            const unsigned long long upto_me = bmask & (lanemask_lt() | (1ull << lane));
+            const int seg = __popcll(upto_me) - 1;
+            // 3. order-preserving segmented inclusive scan
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const R other = wave_shfl_up(val, d);
+                const int oseg = __shfl_up(seg, d, WAVE);
+                if (ok && lane >= d && oseg == seg) {
+                    R tmp;
+                    fat_combine(comb, other, val, tmp);
+                    val = tmp;
+                }
+            }
+            // 4. the last lane of each segment publishes its aggregate
+            const bool tail = ok && ((lane + 1 == (int)cnt) || ((bmask >> (lane + 1)) & 1ull));
+            if (tail) {
+                const int first = 63 - __builtin_clzll(upto_me);  // lane of my segment's boundary
+                segs[seg].agg = val;
+                segs[seg].len = (uint32_t)(lane - first + 1);
+            }
+            const uint32_t n_segs = (uint32_t)__popcll(bmask);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // 5. sequential part: one step per segment
+            if (lane == 0) {
+                for (uint32_t u = 0; u < n_segs; u++) ffat_fold(st, tree, acc, used, g, segs[u].agg, segs[u].len, comb, emit, ctr);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // 6. the windows fired by this chunk leave together
+            emit.flush_wave();
+            if (cnt < WAVE) break;
+            reg = nreg;
+            ok = nok;
+        }
+        if (lay.tree_nodes != 0) {
+            for (uint32_t k = lane; k < 2 * g.tree_cap; k += WAVE) gtree[k] = ltree[k];
+        }
+        if (g.is_tb && lay.acc_slots != 0) {
+            for (uint32_t k = lane; k < g.acc_cap; k += WAVE) {
+                gacc[k] = lacc[k];
+                gused[k] = lused[k];
+            }
+        }
+        if (lane == 0) states[slot] = st;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -214,11 +464,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         FFATKeyState<R> st = states[slot];
         if (!st.seen) continue;
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
+        GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
         // keys are stored as 64-bit values in the table
         const auto key = (decltype(cf_key(st.partial)))table[slot];
         if (!g.is_tb) {
             if (st.pcount > 0) {
-                ffat_complete_pane(st, tree, g, key, st.partial, comb, out, out_count, ctr);
+                ffat_complete_pane(st, tree, g, key, st.partial, comb, emit);
                 st.pcount = 0;
             }
         } else {
@@ -232,7 +483,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     used[a] = 0;
                 }
                 pane.setControlFields(key, st.last_quantum, (st.last_quantum + 1) * g.pane_len - 1);
-                ffat_complete_pane(st, tree, g, key, pane, comb, out, out_count, ctr);
+                ffat_complete_pane(st, tree, g, key, pane, comb, emit);
                 st.last_quantum++;
             }
         }
@@ -244,15 +495,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             fat_query_circular(tree, g.tree_cap, (uint32_t)(first & (g.tree_cap - 1)), cnt < g.win_panes ? cnt : g.win_panes, res, comb);
             res.setControlFields(key, st.next_lwid, cf_ts(res));
             st.next_lwid++;
-            ffat_emit(out, out_count, g, ctr, res);
+            emit(res);
         }
         states[slot] = st;
     }
 }
 
 // clamp the result count to the capacity and mirror it for the host
-__global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatile uint32_t* mirror) {
+__global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatile uint32_t* mirror, uint32_t* n_long = nullptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (n_long) *n_long = 0;  // ready for the next batch (same stream)
         uint32_t c = out_hdr->count;
         if (c > cap) c = cap;
         out_hdr->count = c;
@@ -314,6 +566,17 @@ public:
         idx_.resize(batch_cap_);
         counters_.resize(1);
         WF_HIP_CHECK(hipMemset(counters_.data(), 0, sizeof(FFATCounters)));
+        long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
+        n_long_.resize(1);
+        WF_HIP_CHECK(hipMemset(n_long_.data(), 0, sizeof(uint32_t)));
+        // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
+        // (60 KB of dynamic LDS per block of 4 waves)
+        long_layout_ = FFATLongLayout<R>::choose(g_.tree_cap, g_.acc_cap, g_.is_tb != 0, (60 * 1024) / (BLOCK_THREADS / WAVE));
+        long_lds_bytes_ = (BLOCK_THREADS / WAVE) * long_layout_.wave_bytes();
+        if (long_lds_bytes_ > 64 * 1024) failwith("Key_FFAT_GPU: result type too large for the LDS staging buffers");
+        // the memsets run on the null stream and may return before they complete; the engine's kernels run on
+        // a non-blocking stream that does not order itself after them
+        WF_HIP_CHECK(hipStreamSynchronize(nullptr));
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), out_capacity, pool_slabs));
     }
@@ -336,10 +599,17 @@ public:
             const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
-                               out->template data<R>(), out->device_count_ptr(), counters_.data(), lift_, comb_);
-            kernels += 2 + sorter_.kernels_per_sort(slot_bits_ + 1);
+                               out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), lift_,
+                               comb_);
+            // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
+            const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
+            hipLaunchKernelGGL((ffat_update_long_kernel<T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
+                               in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
+                               out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), long_layout_,
+                               lift_, comb_);
+            kernels += 3 + sorter_.kernels_per_sort(slot_bits_ + 1);
         }
-        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
+        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data());
         kernels++;
         return out;
     }
@@ -388,6 +658,9 @@ private:
     DeviceBuffer<uint8_t> acc_used_;
     DeviceBuffer<uint32_t> slot_, idx_;
     DeviceBuffer<FFATCounters> counters_;
+    DeviceBuffer<uint32_t> long_heads_, n_long_;
+    FFATLongLayout<R> long_layout_{0, 0};
+    size_t long_lds_bytes_ = 0;
     RadixSorter sorter_;
     std::unique_ptr<BatchPool> out_pool_;
 };

@@ -83,6 +83,9 @@ public:
         idx_.resize(batch_capacity);
         full_.resize(1);
         WF_HIP_CHECK(hipMemset(full_.data(), 0, 4));
+        // the memsets run on the null stream and may return before they complete; the operator's kernels run
+        // on a non-blocking stream that does not order itself after them
+        WF_HIP_CHECK(hipStreamSynchronize(nullptr));
         sorter_.reserve(batch_capacity);
     }
     template <typename T>
