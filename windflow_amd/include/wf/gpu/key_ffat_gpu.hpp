@@ -427,7 +427,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // 5. sequential part: one step per segment
             if (lane == 0) {
-                for (uint32_t u = 0; u < n_segs; u++) ffat_fold(st, tree, acc, used, g, segs[u].agg, segs[u].len, comb, emit, ctr);
+                // one copy of the loop per staging combination, so that the compiler knows which pointers
+                // are LDS (ds_* instructions) and which are global instead of emitting flat accesses
+                auto fold_all = [&](R* tr, R* ac, uint8_t* us) {
+                    for (uint32_t u = 0; u < n_segs; u++) ffat_fold(st, tr, ac, us, g, segs[u].agg, segs[u].len, comb, emit, ctr);
+                };
+                const bool acc_staged = g.is_tb && lay.acc_slots != 0;
+                if (lay.tree_nodes != 0 && acc_staged)
+                    fold_all(ltree, lacc, lused);
+                else if (lay.tree_nodes != 0)
+                    fold_all(ltree, gacc, gused);
+                else if (acc_staged)
+                    fold_all(gtree, lacc, lused);
+                else
+                    fold_all(gtree, gacc, gused);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

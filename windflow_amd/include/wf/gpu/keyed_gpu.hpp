@@ -25,17 +25,24 @@
 namespace wf {
 namespace gpu {
 
+// runs of at least this many tuples of one key go to the wave-per-run kernel
+constexpr uint32_t KEYED_LONG_RUN = 32;
+
 // mode 0: in-place map, 1: out-of-place map, 2: filter flags
 template <int MODE, typename T, typename R, typename F>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     keyed_apply_kernel(const BatchHeader* hdr, T* data, R* out, uint8_t* flags, const uint32_t* sslot, const uint32_t* sidx, char* states,
-                       size_t state_size, uint32_t* table_full, F f) {
+                       size_t state_size, uint32_t* table_full, uint32_t* long_heads, uint32_t* n_long, F f) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
         if (i > 0 && sslot[i - 1] == slot) continue;
         if (slot == 0xffffffffu) {
             atomicAdd(table_full, 1u);
+            continue;
+        }
+        if (i + KEYED_LONG_RUN - 1 < n && sslot[i + KEYED_LONG_RUN - 1] == slot) {  // left to the wave-per-run kernel
+            long_heads[atomicAdd(n_long, 1u)] = i;
             continue;
         }
         char* st = states + (size_t)slot * state_size;
@@ -57,6 +64,111 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 flags[p] = keep ? 1 : 0;
             }
         }
+    }
+}
+
+// lane 0 of a wave applies the user function to the `cnt` staged tuples of a chunk, in order
+template <int MODE, typename T, typename R, typename F>
+__device__ __forceinline__ void keyed_apply_chunk(T* stage, R* rstage, uint8_t* fstage, uint32_t cnt, char* st, size_t state_size, F& f) {
+    for (uint32_t u = 0; u < cnt; u++) {
+        if constexpr (MODE == 0) {
+            T t = stage[u];
+            f(t, st, state_size);
+            stage[u] = t;
+        } else if constexpr (MODE == 1) {
+            const T t = stage[u];
+            R res{};
+            f(t, res, st, state_size);
+            rstage[u] = res;
+        } else {
+            const T t = stage[u];
+            bool keep = false;
+            f(t, keep, st, state_size);
+            fstage[u] = keep ? 1 : 0;
+        }
+    }
+}
+
+// Long runs (streams with few keys): one wave64 per run.  The 64 lanes gather the next 64 tuples of
+// the run together (and the chunk after that while lane 0 works), the chunk is staged in LDS and, when
+// it fits, so is the key's state: the user function is sequential per key by contract, but its
+// loads and stores then hit LDS instead of paying an HBM/L2 round trip per tuple.  Results are written
+// back by all lanes.  Dynamic LDS per wave: 64 tuples (+ 64 results, MODE 1) + `lds_state` bytes.
+template <int MODE, typename T, typename R, typename F>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    keyed_apply_long_kernel(const BatchHeader* hdr, T* data, R* out, uint8_t* flags, const uint32_t* sslot, const uint32_t* sidx, char* states,
+                            size_t state_size, const uint32_t* long_heads, const uint32_t* n_long, uint32_t lds_state, size_t wave_bytes, F f) {
+    extern __shared__ __align__(16) char keyed_smem[];
+    const uint32_t n = hdr->count;
+    const uint32_t runs = *n_long;
+    const int lane = lane_id();
+    char* my = keyed_smem + (size_t)wave_id() * wave_bytes;
+    T* stage = reinterpret_cast<T*>(my);
+    size_t off = (WAVE * sizeof(T) + 15) & ~size_t(15);
+    R* rstage = reinterpret_cast<R*>(my + off);
+    if (MODE == 1) off += (WAVE * sizeof(R) + 15) & ~size_t(15);
+    uint8_t* fstage = reinterpret_cast<uint8_t*>(my + off);
+    if (MODE == 2) off += WAVE;
+    off = (off + 15) & ~size_t(15);
+    char* lstate = my + off;
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < runs; r += waves_total) {
+        const uint32_t head = long_heads[r];
+        const uint32_t slot = sslot[head];
+        char* gstate = states + (size_t)slot * state_size;
+        if (lds_state != 0) {
+            // state_size is a multiple of 4 when staged (checked on the host)
+            for (uint32_t k = lane; k < state_size / 4; k += WAVE) reinterpret_cast<uint32_t*>(lstate)[k] = reinterpret_cast<const uint32_t*>(gstate)[k];
+        }
+        uint32_t j = head + lane;
+        bool ok = (j < n) && (sslot[j] == slot);
+        uint32_t p = ok ? sidx[j] : 0;
+        T reg{};
+        if (ok) reg = data[p];
+        while (true) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));  // valid lanes are a prefix: the arrays are sorted
+            if (ok) stage[lane] = reg;
+            const uint32_t my_p = p;
+            const bool my_ok = ok;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // next chunk's loads go out now and complete while lane 0 works
+            ok = false;
+            if (cnt == WAVE) {
+                j += WAVE;
+                ok = (j < n) && (sslot[j] == slot);
+                p = ok ? sidx[j] : 0;
+                if (ok) reg = data[p];
+            }
+            if (lane == 0) {
+                // two copies of the loop so that the compiler knows the address space of the state in each
+                // (LDS instructions instead of flat ones when the state is staged)
+                if (lds_state != 0)
+                    keyed_apply_chunk<MODE, T, R, F>(stage, rstage, fstage, cnt, lstate, state_size, f);
+                else
+                    keyed_apply_chunk<MODE, T, R, F>(stage, rstage, fstage, cnt, gstate, state_size, f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (my_ok) {
+                if constexpr (MODE == 0)
+                    data[my_p] = stage[lane];
+                else if constexpr (MODE == 1)
+                    out[my_p] = rstage[lane];
+                else
+                    flags[my_p] = fstage[lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (cnt < WAVE) break;
+        }
+        if (lds_state != 0) {
+            for (uint32_t k = lane; k < state_size / 4; k += WAVE) reinterpret_cast<uint32_t*>(gstate)[k] = reinterpret_cast<const uint32_t*>(lstate)[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -83,6 +195,9 @@ public:
         idx_.resize(batch_capacity);
         full_.resize(1);
         WF_HIP_CHECK(hipMemset(full_.data(), 0, 4));
+        long_heads_.resize(batch_capacity / KEYED_LONG_RUN + 2);
+        n_long_.resize(1);
+        WF_HIP_CHECK(hipMemset(n_long_.data(), 0, 4));
         // the memsets run on the null stream and may return before they complete; the operator's kernels run
         // on a non-blocking stream that does not order itself after them
         WF_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -97,6 +212,17 @@ public:
         return sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
     }
     char* states() const { return states_.data(); }
+    uint32_t* long_heads() const { return long_heads_.data(); }
+    uint32_t* n_long() const { return n_long_.data(); }
+    // dynamic LDS of the long-run kernel for tuples of `tuple_bytes` (+ `extra` staged bytes per tuple):
+    // per wave {bytes, staged state bytes (0 = the state stays in global memory)}
+    std::pair<size_t, uint32_t> long_layout(size_t tuple_bytes, size_t extra_per_tuple) const {
+        size_t base = ((WAVE * tuple_bytes + 15) & ~size_t(15)) + ((WAVE * extra_per_tuple + 15) & ~size_t(15));
+        const size_t budget = (60 * 1024) / (BLOCK_THREADS / WAVE);
+        uint32_t st = 0;
+        if (state_size_ % 4 == 0 && base + state_size_ + 16 <= budget) st = (uint32_t)state_size_;
+        return {base + ((st + 15) & ~size_t(15)), st};
+    }
     size_t state_size() const { return state_size_; }
     uint32_t* table_full_counter() const { return full_.data(); }
     uint32_t read_table_full(hipStream_t s) {
@@ -111,7 +237,7 @@ private:
     int slot_bits_ = 0;
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<char> states_;
-    DeviceBuffer<uint32_t> slot_, idx_, full_;
+    DeviceBuffer<uint32_t> slot_, idx_, full_, long_heads_, n_long_;
     RadixSorter sorter_;
 };
 
@@ -139,20 +265,14 @@ protected:
         const auto sorted = ctx_->template group<tuple_t>(d, s, this->num_kernels_);
         const unsigned grid = gpu::grid_for(upper);
         if constexpr (MODE == 0) {
-            hipLaunchKernelGGL((gpu::keyed_apply_kernel<0, tuple_t, tuple_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
-                               d->template data<tuple_t>(), (tuple_t*)nullptr, (uint8_t*)nullptr, sorted.keys, sorted.vals, ctx_->states(),
-                               ctx_->state_size(), ctx_->table_full_counter(), func_);
-            this->num_kernels_++;
+            launch_apply<tuple_t>(d, (tuple_t*)nullptr, (uint8_t*)nullptr, sorted, upper, grid, s);
             this->emit_device(d);
         } else if constexpr (MODE == 1) {
             if (!out_pool_)
                 out_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, this->cfg_.gpu_id, sizeof(result_t), d->capacity, this->cfg_.pool_slabs));
             gpu::Batch* o = out_pool_->acquire(s);
             WF_HIP_CHECK(hipMemcpyAsync(o->header(), d->header(), sizeof(gpu::BatchHeader), hipMemcpyDeviceToDevice, s));
-            hipLaunchKernelGGL((gpu::keyed_apply_kernel<1, tuple_t, result_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
-                               d->template data<tuple_t>(), o->template data<result_t>(), (uint8_t*)nullptr, sorted.keys, sorted.vals,
-                               ctx_->states(), ctx_->state_size(), ctx_->table_full_counter(), func_);
-            this->num_kernels_++;
+            launch_apply<result_t>(d, o->template data<result_t>(), (uint8_t*)nullptr, sorted, upper, grid, s);
             o->host_hdr = d->host_hdr;
             o->count_on_host = d->count_on_host;
             if (!d->count_on_host)
@@ -164,16 +284,14 @@ protected:
                 out_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, this->cfg_.gpu_id, sizeof(tuple_t), d->capacity, this->cfg_.pool_slabs));
             flags_.resize(d->capacity);
             ws_.resize(gpu::filter_workspace_words(d->capacity));
-            hipLaunchKernelGGL((gpu::keyed_apply_kernel<2, tuple_t, tuple_t, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
-                               d->template data<tuple_t>(), (tuple_t*)nullptr, flags_.data(), sorted.keys, sorted.vals, ctx_->states(),
-                               ctx_->state_size(), ctx_->table_full_counter(), func_);
+            launch_apply<tuple_t>(d, (tuple_t*)nullptr, flags_.data(), sorted, upper, grid, s);
             WF_HIP_CHECK(hipMemsetAsync(ws_.data(), 0, gpu::filter_workspace_words(upper) * sizeof(unsigned long long), s));
             gpu::Batch* o = out_pool_->acquire(s);
             const unsigned cgrid = (unsigned)std::max<size_t>(1, (upper + gpu::FILTER_TILE - 1) / gpu::FILTER_TILE);
             hipLaunchKernelGGL((gpu::filter_compact_kernel<tuple_t, gpu::FlagPredicate<tuple_t>>), dim3(cgrid), dim3(gpu::BLOCK_THREADS), 0, s,
                                d->header(), d->template data<tuple_t>(), o->header(), o->template data<tuple_t>(), o->count_mirror, ws_.data(),
                                gpu::FlagPredicate<tuple_t>{flags_.data()});
-            this->num_kernels_ += 2;
+            this->num_kernels_ += 1;
             o->host_hdr = d->host_hdr;
             o->count_on_host = false;
             d->release(s);
@@ -186,6 +304,24 @@ protected:
     }
 
 private:
+    // short runs: a thread per run; long runs: a wave per run (recorded by the first kernel)
+    template <typename RR>
+    void launch_apply(gpu::Batch* d, RR* out, uint8_t* flags, const gpu::RadixSorter::Sorted& sorted, size_t upper, unsigned grid, hipStream_t s) {
+        hipLaunchKernelGGL((gpu::keyed_apply_kernel<MODE, tuple_t, RR, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
+                           d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
+                           ctx_->table_full_counter(), ctx_->long_heads(), ctx_->n_long(), func_);
+        const auto lay = ctx_->long_layout(sizeof(tuple_t), MODE == 1 ? sizeof(RR) : (MODE == 2 ? 1 : 0));
+        const size_t lds = (gpu::BLOCK_THREADS / gpu::WAVE) * lay.first;
+        if (lds > 64 * 1024) gpu::failwith("keyed GPU operator: tuple type too large for the LDS staging buffers");
+        const unsigned lgrid =
+            (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / gpu::KEYED_LONG_RUN / (gpu::BLOCK_THREADS / gpu::WAVE) + 1));
+        hipLaunchKernelGGL((gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>), dim3(lgrid), dim3(gpu::BLOCK_THREADS), lds, s, d->header(),
+                           d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
+                           ctx_->long_heads(), ctx_->n_long(), lay.second, lay.first, func_);
+        WF_HIP_CHECK(hipMemsetAsync(ctx_->n_long(), 0, sizeof(uint32_t), s));
+        this->num_kernels_ += 2;
+    }
+
     F func_;
     KeyedGPUConfig kcfg_;
     std::unique_ptr<gpu::KeyedContext> ctx_;
