@@ -44,6 +44,7 @@ def parse_args():
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
                    help="tuples fed per GPU per step")
     p.add_argument("--inflight", type=int, default=6)
+    p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
     p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "dp"), choices=["dp", "keyby"],
                    help="dp: keys are partitioned at ingestion, every GPU aggregates its own sources; "
                         "keyby: tuples are re-partitioned by key across GPUs with Exchange_GPU (RCCL all-to-all over xGMI)")
@@ -51,6 +52,58 @@ def parse_args():
                    help="N>1, dp mode: after the timed run, also time this many steps of the keyby pipeline (reported as an "
                         "extra field; 0 disables)")
     return p.parse_args()
+
+
+def parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(index):
+    """NUMA node of GPU `index` from sysfs (None if unknown)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def rank_cpus(local_rank, world):
+    """CPUs for this rank: an equal share of the CPUs of its GPU's NUMA node (shared with the other ranks whose
+    GPU sits on the same node), or an equal contiguous slice of all allowed CPUs when the topology is unknown."""
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = [gpu_numa_node(i) for i in range(world)]
+    if all(n is not None for n in nodes):
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % nodes[local_rank]) as f:
+                node_cpus = [c for c in parse_cpulist(f.read()) if c in set(allowed)]
+            peers = [i for i in range(world) if nodes[i] == nodes[local_rank]]
+            k = peers.index(local_rank)
+            # the list usually holds two runs (cores, then their SMT siblings): take the k-th share of each run, so a
+            # rank gets whole cores instead of sharing them with the rank that holds the siblings
+            runs, mine = [], []
+            for c in node_cpus:
+                if runs and c == runs[-1][-1] + 1:
+                    runs[-1].append(c)
+                else:
+                    runs.append([c])
+            for run in runs:
+                per = len(run) // len(peers)
+                mine.extend(run[k * per:(k + 1) * per])
+            if len(mine) >= 4:
+                return mine
+        except OSError:
+            pass
+    per = len(allowed) // world
+    return allowed[local_rank * per:(local_rank + 1) * per] if per >= 4 else allowed
 
 
 def timed_steps(pipe, per_source, steps, barrier):
@@ -64,26 +117,30 @@ def timed_steps(pipe, per_source, steps, barrier):
     return time.perf_counter() - t0
 
 
-def run_guarded(fn, timeout_s):
-    """Run fn() in a thread; returns (finished, result_or_exception)."""
-    import threading
+def run_exchange_probe(args, world, limit_s=240):
+    """Time a few steps of the keyby pipeline in a child process; returns a small dict for the JSON line."""
+    import subprocess
 
-    box = {}
-
-    def body():
-        try:
-            box["r"] = fn()
-        except BaseException as e:  # noqa: BLE001
-            box["e"] = e
-
-    t = threading.Thread(target=body, daemon=True)
-    t.start()
-    t.join(timeout_s)
-    if t.is_alive():
-        return False, None
-    if "e" in box:
-        return True, box["e"]
-    return True, box["r"]
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+    env.pop("WF_BENCH_FORCE_PROBE", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.exchange_probe_steps), "--warmup", "1",
+           "--parallelism", "keyby", "--exchange-probe-steps", "0", "--pipeline", "win_agg", "--sources", str(args.sources),
+           "--batch", str(args.batch), "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
+           "--tuples-per-step", str(args.tuples_per_step), "--inflight", str(args.inflight), "--no-cpu-partition"]
+    if args.count_based:
+        cmd.append("--count-based")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"status": "timeout"}
+    if r.returncode != 0:
+        return {"status": "failed (exit %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            d = json.loads(line)
+            return {"status": "ok", "tuples_per_s": d["value"], "steps": d["steps"], "p99_latency_us": d["p99_latency_us"]}
+    return {"status": "ok (this rank printed no result)"}
 
 
 def main():
@@ -97,6 +154,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
+    if world > 1 and not args.no_cpu_partition:
+        # Give every rank its own contiguous slice of the CPUs this job may use (the runtime's source, operator
+        # and sink threads inherit it): on a two-socket node that keeps the pinned slabs and the threads that
+        # fill them on the socket the rank's GPU hangs off, and ranks do not steal each other's cores.
+        try:
+            os.sched_setaffinity(0, rank_cpus(local_rank, world))
+        except (AttributeError, OSError):
+            pass
 
     import windflow_amd
 
@@ -139,36 +204,13 @@ def main():
         dist.all_reduce(lat, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # Secondary measurement (never part of `value`): the same job with the cross-GPU KeyBy exchange in the
-    # data path.  Guarded by a wall-clock limit so that a fabric problem cannot take the headline number down.
+    # Secondary measurement (never part of `value`): the same job with the cross-GPU KeyBy exchange in the data
+    # path.  It runs in CHILD processes (one per rank, own rendezvous port) under a wall-clock limit, so that a
+    # fabric problem - an RCCL abort, a hang inside a collective - cannot take the headline number down.
     probe = None
-    hung = False
     if (world > 1 or os.environ.get("WF_BENCH_FORCE_PROBE")) and args.pipeline == "win_agg" and args.parallelism == "dp" \
             and args.exchange_probe_steps > 0:
-        def exchange_probe():
-            from windflow_amd import parallel as wfpar
-
-            tr = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
-            p2 = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0,
-                                    args.inflight, tr)
-            p2.step(per_source)
-            el = timed_steps(p2, per_source, args.exchange_probe_steps, barrier)
-            st = p2.stats()
-            p2.close()
-            return el, st
-
-        finished, r = run_guarded(exchange_probe, 150.0)
-        if not finished:
-            hung = True
-            probe = {"status": "timeout"}
-        elif isinstance(r, BaseException):
-            probe = {"status": "error: %s" % (r,)}
-        else:
-            el = r[0]
-            probe = {"status": "ok", "tuples_per_s": tuples_per_step_gpu * world * args.exchange_probe_steps / el,
-                     "steps": args.exchange_probe_steps, "p99_latency_us": r[1]["latency_p99_us"]}
-
-
+        probe = run_exchange_probe(args, world)
     if rank == 0:
         total_tuples = tuples_per_step_gpu * world * args.steps
         value = total_tuples / elapsed
@@ -202,10 +244,6 @@ def main():
             },
             **({"keyby_exchange_probe": probe} if probe is not None else {}),
         }), flush=True)
-    if hung:
-        # a rank is still blocked inside a collective: leave without running destructors
-        sys.stdout.flush()
-        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

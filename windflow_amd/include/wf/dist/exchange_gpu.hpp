@@ -52,6 +52,8 @@ public:
         round(nullptr, false);
     }
     uint64_t rounds() const { return rounds_; }
+    uint64_t bytes_received() const { return bytes_exchanged_; }
+    uint64_t max_link_bytes_per_round() const { return max_link_bytes_; }
 
 protected:
     void gpu_init() override {
@@ -68,6 +70,7 @@ private:
     static constexpr size_t META = gpu::MAX_PARTITIONS + 5;  // counts[], done, step, watermark, created_ns, batch capacity
 
     void round(gpu::Batch* d, bool done) {
+        gpu::TraceRange trace("wf:exchange_round");
         const int world = tr_->world(), me = tr_->rank();
         hipStream_t s = this->stream();
         std::vector<gpu::Batch*> parts;
@@ -104,7 +107,7 @@ private:
         // what I receive, rank-major
         size_t total = 0;
         bool all_done = true;
-        uint64_t min_step = UINT64_MAX, wm = 0, created = 0;
+        uint64_t min_step = UINT64_MAX, created = 0;
         size_t recv_cnt[dist::MAX_WORLD];
         for (int r = 0; r < world; r++) {
             const uint64_t* row = all + (size_t)r * META;
@@ -112,7 +115,9 @@ private:
             total += recv_cnt[r];
             all_done = all_done && row[gpu::MAX_PARTITIONS + 0] != 0;
             min_step = std::min(min_step, row[gpu::MAX_PARTITIONS + 1]);
-            wm = std::max(wm, row[gpu::MAX_PARTITIONS + 2]);
+            // per-rank high marks; what I forward is the LOW watermark: the minimum over the ranks still producing
+            rank_wm_[r] = std::max(rank_wm_[r], row[gpu::MAX_PARTITIONS + 2]);
+            rank_done_[r] = row[gpu::MAX_PARTITIONS + 0] != 0;
             cap_ = std::max<size_t>(cap_, (size_t)row[gpu::MAX_PARTITIONS + 4]);
             if (row[gpu::MAX_PARTITIONS + 3] != 0 && recv_cnt[r] > 0) created = created == 0 ? row[gpu::MAX_PARTITIONS + 3] : std::min(created, row[gpu::MAX_PARTITIONS + 3]);
         }
@@ -123,6 +128,11 @@ private:
                     any_traffic = true;
                     break;
                 }
+        uint64_t wm = UINT64_MAX;
+        for (int r = 0; r < world; r++)
+            if (!rank_done_[r]) wm = std::min(wm, rank_wm_[r]);
+        if (wm == UINT64_MAX)
+            for (int r = 0; r < world; r++) wm = (r == 0) ? rank_wm_[r] : std::max(wm, rank_wm_[r]);
         const uint64_t step_out = take_global_step(min_step);
         gpu::Batch* out = nullptr;
         if (any_traffic) {
@@ -142,6 +152,9 @@ private:
             }
             tr_->all_to_all_v(sl, s);
             bytes_exchanged_ += off * sizeof(tuple_t);
+            // xGMI is point to point: the exchange is bound by the busiest link, not by the total
+            for (int p = 0; p < world; p++)
+                if (p != me) max_link_bytes_ = std::max<uint64_t>(max_link_bytes_, std::max(sl.send_bytes[p], sl.recv_bytes[p]));
         } else if (step_out != 0) {
             out = acquire_out(0);
         }
@@ -198,7 +211,9 @@ private:
     std::vector<std::unique_ptr<gpu::BatchPool>> retired_pools_;
     size_t my_cap_ = 0, cap_ = 0, out_cap_ = 0;
     uint64_t seq_ = 0, rounds_ = 0, bytes_exchanged_ = 0, last_round_us_ = 0;
-    uint64_t local_step_done_ = 0, announced_step_ = 0;
+    uint64_t local_step_done_ = 0, announced_step_ = 0, max_link_bytes_ = 0;
+    uint64_t rank_wm_[dist::MAX_WORLD] = {};
+    bool rank_done_[dist::MAX_WORLD] = {};
     std::map<uint64_t, size_t> punct_seen_;
     bool finished_ = false;
 };

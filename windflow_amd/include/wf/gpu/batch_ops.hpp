@@ -21,6 +21,7 @@
 
 #include "../simple_operator.hpp"
 #include "hip_utils.hpp"
+#include "trace.hpp"
 
 namespace wf {
 
@@ -135,6 +136,7 @@ private:
                     f.dev->host_hdr.count = *f.dev->count_mirror;
                     f.dev->count_on_host = true;
                 }
+                gpu::TraceRange tr("wf:drain_batch");
                 gpu::Batch* h = pool_->acquire_host();
                 h->host_hdr = f.dev->host_hdr;
                 f.dev->ready.wait_on(*stream_);
@@ -343,6 +345,7 @@ public:
             case EDGE_DEVICE_BATCH: {
                 gpu::Batch* d = static_cast<gpu::Batch*>(msg);
                 d->ready.wait_on(*stream_);
+                gpu::TraceRange tr("wf:enqueue_kernels");
                 process_device(d);
                 break;
             }
@@ -398,6 +401,7 @@ private:
     }
     // host batch -> device batch (async), then run the operator on it
     void ship(gpu::Batch* h) {
+        gpu::TraceRange tr("wf:ship_batch");
         if (!dev_in_pool_)
             dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), h->capacity, cfg_.pool_slabs));
         gpu::Batch* d = dev_in_pool_->acquire(stream());
