@@ -44,6 +44,8 @@ def parse_args():
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
                    help="tuples fed per GPU per step")
     p.add_argument("--inflight", type=int, default=6)
+    p.add_argument("--agg-replicas", type=int, default=int(os.environ.get("WF_BENCH_AGG_REPLICAS", "0")),
+                   help="keyby mode: Key_FFAT_GPU replicas behind the exchange (0: default)")
     p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
     p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "dp"), choices=["dp", "keyby"],
                    help="dp: keys are partitioned at ingestion, every GPU aggregates its own sources; "
@@ -183,7 +185,7 @@ def main():
 
             transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
         pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0, args.inflight,
-                                  transport)
+                                  transport, args.agg_replicas)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 

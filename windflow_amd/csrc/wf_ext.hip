@@ -274,8 +274,8 @@ public:
     // sources).  With a transport the tuples are re-partitioned by key across the ranks first (Exchange_GPU:
     // RCCL all-to-all over xGMI) and then across the local replicas (device KeyBy).
     WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
-                   size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr)
-        : n_sources_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
+                   size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr, size_t agg_replicas = 0)
+        : n_sources_(n_sources), n_sinks_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<SinkTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
@@ -296,16 +296,20 @@ public:
         cfg.batch_len = batch_len;
         cfg.pool_slabs = inflight;
         if (transport) {
-            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withLocalLanes(n_sources).withGPUConfiguration(gpu_id)
+            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources).withGPUConfiguration(gpu_id)
                             .withInFlightBatches(inflight).build_unique();
             mp.add(*exchange_);
             wcfg.lanes_are_key_disjoint = false;
             // hash partitioning is only balanced on average: leave headroom in the per-replica key tables and
             // in the result batches (a replica may see up to world x batch_len tuples in one batch)
-            wcfg.max_keys = n_keys + n_keys / 4 + 1024;
+            // behind the exchange every batch holds a whole round (up to world x batch_len tuples): a few fat
+            // aggregation replicas keep the kernels large; many thin ones would drown in launches
+            n_sinks_ = agg_replicas ? agg_replicas : 1;  // measured on one MI355X: 1 replica 844 M t/s, 2: 559, 4: 507, 8: 304
+            wcfg.max_keys = n_keys * n_sources / n_sinks_;
+            wcfg.max_keys += wcfg.max_keys / 4 + 1024;
             wcfg.out_capacity = batch_len * world;
         }
-        kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sources, "key_ffat_gpu", cfg));
+        kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg));
         mp.add(*kff_);
         auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
             double s = 0.0;
@@ -318,7 +322,7 @@ public:
             }
             if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
         };
-        sink_ = BatchSink_Builder(sink_f).withName("sink").withParallelism(n_sources).build_unique();
+        sink_ = BatchSink_Builder(sink_f).withName("sink").withParallelism(n_sinks_).build_unique();
         mp.chain_sink(*sink_);
         latency_ = sink_->latency();
         graph_.start();
@@ -328,7 +332,7 @@ public:
         py::gil_scoped_release rel;
         step_id_++;
         for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
-        barrier_->wait(step_id_, (int)n_sources_);
+        barrier_->wait(step_id_, (int)n_sinks_);
     }
     void close() {
         if (closed_) return;
@@ -366,7 +370,7 @@ public:
     std::string dot() { return graph_.get_DOTGraph(); }
 
 private:
-    size_t n_sources_;
+    size_t n_sources_, n_sinks_;
     std::unique_ptr<wfbench::StepGate[]> gates_;
     PipeGraph graph_;
     std::shared_ptr<SinkTotals> totals_;
@@ -487,9 +491,10 @@ PYBIND11_MODULE(_C, m) {
     m.def("exchange_local_run", &exchange_local_run, py::arg("gpu_id"), py::arg("world"), py::arg("n_per_rank"), py::arg("n_keys"),
           py::arg("batch_len"));
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
-        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>>(), py::arg("gpu_id"),
-             py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"), py::arg("time_based") = false,
-             py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr)
+        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t>(),
+             py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"),
+             py::arg("time_based") = false, py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr,
+             py::arg("agg_replicas") = 0)
         .def("step", &WinAggPipeline::step)
         .def("close", &WinAggPipeline::close)
         .def("stats", &WinAggPipeline::stats)
