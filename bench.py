@@ -119,23 +119,41 @@ def timed_steps(pipe, per_source, steps, barrier):
     return time.perf_counter() - t0
 
 
-def run_exchange_probe(args, world, limit_s=240):
+def run_exchange_probe(args, world, limit_s=90):
     """Time a few steps of the keyby pipeline in a child process; returns a small dict for the JSON line."""
     import subprocess
 
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
     env.pop("WF_BENCH_FORCE_PROBE", None)
+    # the children rendezvous among themselves: rank 0's child hosts the store on the new port (under torchrun the
+    # workers would otherwise look for the launcher's store there)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.exchange_probe_steps), "--warmup", "1",
            "--parallelism", "keyby", "--exchange-probe-steps", "0", "--pipeline", "win_agg", "--sources", str(args.sources),
            "--batch", str(args.batch), "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
            "--tuples-per-step", str(args.tuples_per_step), "--inflight", str(args.inflight), "--no-cpu-partition"]
     if args.count_based:
         cmd.append("--count-based")
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
-    except subprocess.TimeoutExpired:
-        return {"status": "timeout"}
+    print("[bench] timed run done; probing the keyby exchange in a child process (limit %d s)" % limit_s, file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t_end = time.time() + limit_s
+    while True:
+        try:
+            out, err = child.communicate(timeout=30)
+            break
+        except subprocess.TimeoutExpired:
+            if time.time() >= t_end:
+                child.kill()
+                out, err = child.communicate()
+                return {"status": "timeout", "stderr_tail": (err or "")[-300:]}
+            print("[bench] exchange probe still running", file=sys.stderr, flush=True)
+
+    class R:  # noqa: D401 - tiny result holder
+        pass
+
+    r = R()
+    r.returncode, r.stdout, r.stderr = child.returncode, out, err
     if r.returncode != 0:
         return {"status": "failed (exit %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
     for line in reversed(r.stdout.splitlines()):
@@ -150,9 +168,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_slot = local_rank
+    if os.environ.get("WF_BENCH_DEVICE"):  # rehearsal of an N-rank launch on a box with fewer GPUs: every rank uses this GPU
+        local_rank = int(os.environ["WF_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo prints a connection banner on stdout; stdout is reserved for the JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
@@ -161,7 +192,7 @@ def main():
         # and sink threads inherit it): on a two-socket node that keeps the pinned slabs and the threads that
         # fill them on the socket the rank's GPU hangs off, and ranks do not steal each other's cores.
         try:
-            os.sched_setaffinity(0, rank_cpus(local_rank, world))
+            os.sched_setaffinity(0, rank_cpus(cpu_slot, world))
         except (AttributeError, OSError):
             pass
 
