@@ -347,6 +347,7 @@ public:
                 d->ready.wait_on(*stream_);
                 gpu::TraceRange tr("wf:enqueue_kernels");
                 process_device(d);
+                WF_HIP_CHECK(hipGetLastError());  // a refused launch (bad grid, too much LDS) must not pass silently
                 break;
             }
         }
@@ -413,6 +414,7 @@ private:
         d->count_on_host = true;
         h->release(stream());
         process_device(d);
+        WF_HIP_CHECK(hipGetLastError());  // a refused launch (bad grid, too much LDS) must not pass silently
     }
 
     std::unique_ptr<gpu::Stream> stream_;

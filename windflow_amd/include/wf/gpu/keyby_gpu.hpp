@@ -164,6 +164,7 @@ public:
         }
         std::vector<gpu::Batch*> outs;
         part_.partition(d, s, outs, kernels_);
+        WF_HIP_CHECK(hipGetLastError());
         d->release(s);
         for (size_t p = 0; p < n_dest_; p++) {
             outs[p]->ready.record(s);
