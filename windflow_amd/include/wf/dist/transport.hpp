@@ -240,11 +240,13 @@ public:
         fabric_->sync();
         std::vector<double> acc(n, 0.0), tmp(n);
         for (int r = 0; r < world_; r++) {
-            WF_HIP_CHECK(hipMemcpy(tmp.data(), fabric_->reduce_[r].first, n * sizeof(double), hipMemcpyDefault));
+            WF_HIP_CHECK(hipMemcpyAsync(tmp.data(), fabric_->reduce_[r].first, n * sizeof(double), hipMemcpyDefault, s));
+            WF_HIP_CHECK(hipStreamSynchronize(s));
             for (size_t i = 0; i < n; i++) acc[i] += tmp[i];
         }
         fabric_->sync();  // everybody has read the inputs
-        WF_HIP_CHECK(hipMemcpy(dev, acc.data(), n * sizeof(double), hipMemcpyDefault));
+        WF_HIP_CHECK(hipMemcpyAsync(dev, acc.data(), n * sizeof(double), hipMemcpyDefault, s));
+        WF_HIP_CHECK(hipStreamSynchronize(s));
         fabric_->sync();
     }
 

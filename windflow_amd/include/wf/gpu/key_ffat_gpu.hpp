@@ -23,7 +23,9 @@
 //  * end-of-stream runs ffat_flush_kernel on the device (the reference falls back
 //    to the CPU: win_seqffat_gpu.hpp:543-660).
 #pragma once
+#include <map>
 #include <numeric>
+#include <tuple>
 
 #include "batch_ops.hpp"
 #include "flatfat_gpu.hpp"
@@ -563,47 +565,90 @@ public:
         while ((1ull << slot_bits_) < table_cap_) slot_bits_++;
         batch_cap_ = batch_capacity;
         WF_HIP_CHECK(hipSetDevice(device_));
+        // never the legacy (null) stream: its implicit dependencies would break stream captures running in other threads
+        Stream init;
         table_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemset(table_.data(), 0xff, table_cap_ * sizeof(unsigned long long)));
+        WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_cap_ * sizeof(unsigned long long), init.get()));
         states_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemset(states_.data(), 0, table_cap_ * sizeof(FFATKeyState<R>)));
+        WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, table_cap_ * sizeof(FFATKeyState<R>), init.get()));
         trees_.resize((size_t)table_cap_ * 2 * g_.tree_cap);
-        WF_HIP_CHECK(hipMemset(trees_.data(), 0, trees_.bytes()));
+        WF_HIP_CHECK(hipMemsetAsync(trees_.data(), 0, trees_.bytes(), init.get()));
         if (g_.is_tb) {
             accs_.resize((size_t)table_cap_ * g_.acc_cap);
-            WF_HIP_CHECK(hipMemset(accs_.data(), 0, accs_.bytes()));
+            WF_HIP_CHECK(hipMemsetAsync(accs_.data(), 0, accs_.bytes(), init.get()));
             acc_used_.resize((size_t)table_cap_ * g_.acc_cap);
-            WF_HIP_CHECK(hipMemset(acc_used_.data(), 0, acc_used_.bytes()));
+            WF_HIP_CHECK(hipMemsetAsync(acc_used_.data(), 0, acc_used_.bytes(), init.get()));
         }
         slot_.resize(batch_cap_);
         idx_.resize(batch_cap_);
         counters_.resize(1);
-        WF_HIP_CHECK(hipMemset(counters_.data(), 0, sizeof(FFATCounters)));
+        WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(FFATCounters), init.get()));
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
         n_long_.resize(1);
-        WF_HIP_CHECK(hipMemset(n_long_.data(), 0, sizeof(uint32_t)));
+        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, sizeof(uint32_t), init.get()));
         // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
         // (60 KB of dynamic LDS per block of 4 waves)
         long_layout_ = FFATLongLayout<R>::choose(g_.tree_cap, g_.acc_cap, g_.is_tb != 0, (60 * 1024) / (BLOCK_THREADS / WAVE));
         long_lds_bytes_ = (BLOCK_THREADS / WAVE) * long_layout_.wave_bytes();
         if (long_lds_bytes_ > 64 * 1024) failwith("Key_FFAT_GPU: result type too large for the LDS staging buffers");
-        // the memsets run on the null stream and may return before they complete; the engine's kernels run on
-        // a non-blocking stream that does not order itself after them
-        WF_HIP_CHECK(hipStreamSynchronize(nullptr));
+        // the engine's kernels run on another stream: wait for the initialisation here
+        init.sync();
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), out_capacity, pool_slabs));
     }
 
+    ~KeyedFFATEngine() {
+        for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+    }
+    KeyedFFATEngine(const KeyedFFATEngine&) = delete;
+    KeyedFFATEngine& operator=(const KeyedFFATEngine&) = delete;
+
     const FFATGeometry& geometry() const { return g_; }
     size_t device_bytes() const { return table_.bytes() + states_.bytes() + trees_.bytes() + accs_.bytes() + acc_used_.bytes(); }
 
-    // enqueue the processing of `in` on `s`; returns the batch of fired windows (count on device)
+    // enqueue the processing of `in` on `s`; returns the batch of fired windows (count on device).
+    // With WF_HIP_GRAPHS=1 the per-batch sequence (header clear, slot assignment, 3 kernels per sort
+    // pass, the two update kernels, finalize: 10-16 launches) is captured ONCE per (input slab, output
+    // slab, size) into a hipGraph and replayed with a single hipGraphLaunch; slabs come from small
+    // bounded pools, so a handful of graphs covers the steady state.  Measured on MI355X / ROCm 7.0
+    // (profiles/r1_latency_sweep/hip_graphs.txt) replay is NOT faster than the plain launches - 16 Ki
+    // batches: 324-353 vs 362 M tuples/s, 256 Ki: 1035-1105 vs 1130 - so it is off by default.
     Batch* process(Batch* in, hipStream_t s, uint64_t& kernels) {
         const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
         if (upper > batch_cap_) failwith("Key_FFAT_GPU: input batch larger than the configured batch capacity");
         Batch* out = out_pool_->acquire(s);
         out->host_hdr = in->host_hdr;
         out->count_on_host = false;
+        const uint64_t n_launch = 2 + (upper > 0 ? 3 + sorter_.kernels_per_sort(slot_bits_ + 1) : 0);
+        kernels += n_launch - 1;
+        if (use_graphs_) {
+            const GraphKey key{in->slab, out->slab, upper};
+            auto it = graphs_.find(key);
+            if (it == graphs_.end() && graphs_.size() < MAX_GRAPHS) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                // captured on a stream of its own that never carries real work or event dependencies
+                if (!capture_stream_) capture_stream_.reset(new Stream());
+                WF_HIP_CHECK(hipStreamBeginCapture(capture_stream_->get(), hipStreamCaptureModeThreadLocal));
+                enqueue(in, out, upper, capture_stream_->get());
+                WF_HIP_CHECK(hipStreamEndCapture(capture_stream_->get(), &graph));
+                WF_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                WF_HIP_CHECK(hipGraphDestroy(graph));
+                it = graphs_.emplace(key, exec).first;
+            }
+            if (it != graphs_.end()) {
+                WF_HIP_CHECK(hipGraphLaunch(it->second, s));
+                graph_launches_++;
+                return out;
+            }
+        }
+        enqueue(in, out, upper, s);
+        return out;
+    }
+    uint64_t graph_launches() const { return graph_launches_; }
+
+private:
+    void enqueue(Batch* in, Batch* out, size_t upper, hipStream_t s) {
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
         if (upper > 0) {
             const unsigned grid = grid_for(upper);
@@ -620,13 +665,11 @@ public:
                                in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), long_layout_,
                                lift_, comb_);
-            kernels += 3 + sorter_.kernels_per_sort(slot_bits_ + 1);
         }
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data());
-        kernels++;
-        return out;
     }
 
+public:
     // end of stream: emit every incomplete window.  The table is flushed in slot
     // ranges sized so that the windows of a range always fit one output batch;
     // the caller hands each batch downstream before asking for the next one, so
@@ -673,6 +716,22 @@ private:
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;
     FFATLongLayout<R> long_layout_{0, 0};
+    // hipGraph cache
+    struct GraphKey {
+        const void* in;
+        const void* out;
+        size_t n;
+        bool operator<(const GraphKey& o) const { return std::tie(in, out, n) < std::tie(o.in, o.out, o.n); }
+    };
+    static constexpr size_t MAX_GRAPHS = 256;
+    std::map<GraphKey, hipGraphExec_t> graphs_;
+    std::unique_ptr<Stream> capture_stream_;
+    bool use_graphs_ = env_flag("WF_HIP_GRAPHS", false);
+    uint64_t graph_launches_ = 0;
+    static bool env_flag(const char* name, bool dflt) {
+        const char* v = std::getenv(name);
+        return v ? std::atoi(v) != 0 : dflt;
+    }
     size_t long_lds_bytes_ = 0;
     RadixSorter sorter_;
     std::unique_ptr<BatchPool> out_pool_;

@@ -184,23 +184,24 @@ class KeyedContext {
 public:
     KeyedContext(size_t max_keys, size_t state_size, size_t batch_capacity, int device) : state_size_(state_size ? state_size : 1) {
         WF_HIP_CHECK(hipSetDevice(device));
+        // never the legacy (null) stream: its implicit dependencies would break stream captures running in other threads
+        Stream init;
         table_cap_ = 2;
         while (table_cap_ < 2 * max_keys) table_cap_ <<= 1;
         while ((1ull << slot_bits_) < table_cap_) slot_bits_++;
         table_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemset(table_.data(), 0xff, table_.bytes()));
+        WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_.bytes(), init.get()));
         states_.resize(table_cap_ * state_size_);
-        WF_HIP_CHECK(hipMemset(states_.data(), 0, states_.bytes()));
+        WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, states_.bytes(), init.get()));
         slot_.resize(batch_capacity);
         idx_.resize(batch_capacity);
         full_.resize(1);
-        WF_HIP_CHECK(hipMemset(full_.data(), 0, 4));
+        WF_HIP_CHECK(hipMemsetAsync(full_.data(), 0, 4, init.get()));
         long_heads_.resize(batch_capacity / KEYED_LONG_RUN + 2);
         n_long_.resize(1);
-        WF_HIP_CHECK(hipMemset(n_long_.data(), 0, 4));
-        // the memsets run on the null stream and may return before they complete; the operator's kernels run
-        // on a non-blocking stream that does not order itself after them
-        WF_HIP_CHECK(hipStreamSynchronize(nullptr));
+        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 4, init.get()));
+        // the operator's kernels run on another stream: wait for the initialisation here
+        init.sync();
         sorter_.reserve(batch_capacity);
     }
     template <typename T>
