@@ -186,6 +186,60 @@ int main(int argc, char** argv) {
             failures += !ok;
         }
     }
+    // ---- D: GPU operators around split and merge: batches are turned back into tuples where the graph forks ----
+    for (size_t run = 0; run < runs; run++) {
+        const size_t p1 = (size_t)dp(rng), p2 = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        PipeGraph g("keyed_d", Mode::DEFAULT);
+        auto srcA = BatchSource_Builder(Gen(n, keys)).withName("srcA").withParallelism(1).withBatch(batch).build_unique();
+        auto srcB = BatchSource_Builder(Gen(n, keys)).withName("srcB").withParallelism(1).withBatch(batch).build_unique();
+        MultiPipe& a = g.add_source(*srcA);
+        MultiPipe& b = g.add_source(*srcB);
+        auto mapA = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value * 2; }).withName("dbl").withParallelism(p1).build_unique();
+        auto mapB = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value + 100; }).withName("plus").withParallelism(p2).build_unique();
+        a.add(*mapA);
+        b.add(*mapB);
+        MultiPipe& m = a.merge(b);
+        auto fil = FilterGPU_Builder([] __host__ __device__(const tuple_t& t) { return t.value % 3 == 0; }).withName("thirds").withParallelism(p1)
+                       .withBatch(batch).build_unique();
+        m.add(*fil);
+        m.split([](const tuple_t& t) -> size_t { return t.value < 0 ? 0 : 1; }, 2);
+        long neg_sum = 0, neg_cnt = 0, pos_sum = 0, pos_cnt = 0;
+        auto neg_map = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = -t.value; }).withName("abs").withParallelism(p2).withBatch(batch)
+                           .build_unique();
+        m.select(0).add(*neg_map);
+        Sink s0 = Sink_Builder([&](std::optional<tuple_t>& o) {
+                      if (o) {
+                          neg_sum += o->value;
+                          neg_cnt++;
+                      }
+                  }).withParallelism(1).build();
+        m.select(0).add_sink(s0);
+        Sink s1 = Sink_Builder([&](std::optional<tuple_t>& o) {
+                      if (o) {
+                          pos_sum += o->value;
+                          pos_cnt++;
+                      }
+                  }).withParallelism(1).build();
+        m.select(1).add_sink(s1);
+        g.run();
+        long e_neg_sum = 0, e_neg_cnt = 0, e_pos_sum = 0, e_pos_cnt = 0;
+        for (auto& t : stream)
+            for (int64_t v : {t.value * 2, t.value + 100}) {
+                if (v % 3 != 0) continue;
+                if (v < 0) {
+                    e_neg_sum += -v;
+                    e_neg_cnt++;
+                } else {
+                    e_pos_sum += v;
+                    e_pos_cnt++;
+                }
+            }
+        const bool ok = neg_sum == e_neg_sum && neg_cnt == e_neg_cnt && pos_sum == e_pos_sum && pos_cnt == e_pos_cnt;
+        cout << "D par=" << p1 << "," << p2 << " batch=" << batch << " neg " << neg_sum << "/" << neg_cnt << " pos " << pos_sum << "/" << pos_cnt
+             << (ok ? "  OK" : "  FAILED") << endl;
+        failures += !ok;
+    }
     (void)EveryThird{};
     return failures == 0 ? 0 : 1;
 }

@@ -165,3 +165,16 @@ def test_win_agg_pipeline_end_to_end(ext):
             total += c[min(per_key, 2 * lw + 8)] - c[2 * lw]
     assert st2["sink_value_sum"] == pytest.approx(2 * total, rel=1e-12)
     assert st2["overflow"] == 0 and st2["table_full"] == 0
+
+
+def test_key_ffat_with_hip_graph_replay(ext, monkeypatch):
+    """WF_HIP_GRAPHS=1: the per-batch kernel sequence is captured once per slab pair and replayed."""
+    monkeypatch.setenv("WF_HIP_GRAPHS", "1")
+    t, vals = make_stream(60000, 500, seed=11)
+    res, ctr = ext.key_ffat_run(t, 12, 4, 0, False, 1024, 4096)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0
+    got = unpack(res)
+    exp = oracle_cb(t, vals, 12, 4)
+    assert len(got) == len(exp)
+    for k, (s, ts) in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9) and got[k][1] == ts
