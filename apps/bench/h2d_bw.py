@@ -39,9 +39,27 @@ def duplex(chunk_mb=10, up=8, down=2, seconds=1.0, busy_kernel=False):
     sd = [torch.cuda.Stream() for _ in range(down)]
     sk = torch.cuda.Stream()
     big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda") if busy_kernel else None
+    def one_round():
+        for s, h, d in zip(su, hu, du):
+            with torch.cuda.stream(s):
+                d.copy_(h, non_blocking=True)
+        for s, h, d in zip(sd, hd, dd):
+            with torch.cuda.stream(s):
+                h.copy_(d, non_blocking=True)
+        if busy_kernel:
+            with torch.cuda.stream(sk):
+                big.add_(1.0)
+
+    for _ in range(20):
+        one_round()
     torch.cuda.synchronize()
-    reps = 40
+    reps = 400
     t0 = time.perf_counter()
+    for _ in range(reps):
+        one_round()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return reps * up * n / dt / 1e9, reps * down * n / dt / 1e9
     for _ in range(reps):
         for s, h, d in zip(su, hu, du):
             with torch.cuda.stream(s):
