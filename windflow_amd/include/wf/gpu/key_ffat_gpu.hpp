@@ -313,11 +313,16 @@ struct FFATSegment {
     uint32_t pad;
 };
 
+// leaves of the per-wave working tree of the bulk path: a chunk completes at most WAVE panes and a
+// window needs the win_panes - 1 panes before them, so bulk mode needs win_panes + WAVE <= FFAT_WORK_LEAVES
+constexpr uint32_t FFAT_WORK_LEAVES = 128;
+
 // LDS layout of one wave of the long-run kernel
 template <typename R>
 struct FFATLongLayout {
     uint32_t tree_nodes;  // 0: the tree stays in global memory
     uint32_t acc_slots;   // 0: the ring of open quanta stays in global memory
+    uint32_t bulk;        // 1: tree_nodes = 2 * FFAT_WORK_LEAVES, a working tree private to the run (bulk path)
     __host__ __device__ static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
     __host__ __device__ size_t segs_off() const { return 0; }
     __host__ __device__ size_t res_off() const { return align16(WAVE * sizeof(FFATSegment<R>)); }
@@ -326,16 +331,62 @@ struct FFATLongLayout {
     __host__ __device__ size_t used_off() const { return acc_off() + align16((size_t)acc_slots * sizeof(R)); }
     __host__ __device__ size_t wave_bytes() const { return used_off() + align16(acc_slots); }
     // stage as much of the per-key state as fits `budget` bytes per wave
-    static FFATLongLayout choose(uint32_t tree_cap, uint32_t acc_cap, bool is_tb, size_t budget) {
-        FFATLongLayout l{0, 0};
-        FFATLongLayout with_acc{0, is_tb ? acc_cap : 0};
+    static FFATLongLayout choose(const FFATGeometry& g, size_t budget) {
+        const uint32_t acc = g.is_tb ? g.acc_cap : 0;
+        FFATLongLayout l{0, 0, 0};
+        FFATLongLayout with_acc{0, acc, 0};
         if (with_acc.wave_bytes() <= budget) l = with_acc;
-        FFATLongLayout with_tree{2 * tree_cap, l.acc_slots};
+        FFATLongLayout with_tree{2 * g.tree_cap, l.acc_slots, 0};
         if (with_tree.wave_bytes() <= budget) l = with_tree;
+        FFATLongLayout with_bulk{2 * FFAT_WORK_LEAVES, acc, 1};
+        if (g.win_panes + WAVE <= FFAT_WORK_LEAVES && with_bulk.wave_bytes() <= budget) l = with_bulk;
         return l;
     }
 };
 
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the value of `v` held by lane `src`
+template <typename X>
+__device__ __forceinline__ X wave_bcast(const X& v, int src) {
+    static_assert(sizeof(X) % 4 == 0, "wave shuffles move 32-bit words");
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(X) / 4; k++) w[k] = __shfl(w[k], src, WAVE);
+    X o;
+    __builtin_memcpy(&o, w, sizeof(X));
+    return o;
+}
+
+// recompute every internal node of a tree from its leaves, one level per step, a lane per node
+template <typename R, typename C>
+__device__ __forceinline__ void fat_rebuild_wave(R* tree, uint32_t cap, const C& comb) {
+    for (uint32_t width = cap >> 1; width >= 1; width >>= 1) {
+        for (uint32_t j = (uint32_t)lane_id(); j < width; j += WAVE) {
+            const uint32_t node = width + j;
+            R tmp;
+            fat_combine(comb, tree[2 * node], tree[2 * node + 1], tmp);
+            tree[node] = tmp;
+        }
+        wave_sync_lds();
+    }
+}
+
+// Long runs: one wave64 per run, exploiting the associativity of the combine.
+//  * all chunks: the 64 lanes gather and LIFT the next 64 tuples of the run together; lanes whose tuples
+//    fall in the same pane (CB) / quantum (TB) form a segment and an order-preserving segmented wave scan
+//    (6 shuffle + combine steps) leaves each segment's aggregate in its last lane;
+//  * bulk path (window of at most 64 panes, in-order chunk, no triggering delay): the panes completed by
+//    the chunk are written side by side as leaves of a 128-leaf working tree private to the run (LDS),
+//    the tree is rebuilt a level per step, and every window fired by the chunk is evaluated by a lane of
+//    its own - nothing is sequential per tuple, per pane or per window;
+//  * otherwise lane 0 folds the segments one by one (same rules as ffat_fold), on the staged tree.
+// The windows fired by a chunk leave with one atomic.
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
@@ -351,29 +402,37 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     R* lacc = reinterpret_cast<R*>(my + lay.acc_off());
     uint8_t* lused = reinterpret_cast<uint8_t*>(my + lay.used_off());
     WaveEmit<R> emit{reinterpret_cast<R*>(my + lay.res_off()), 0u, out, out_count, g.out_cap, ctr};
+    const bool bulk = lay.bulk != 0;
+    constexpr uint32_t CW = FFAT_WORK_LEAVES;
+    // geometry seen by the sequential rules when they work on the private tree
+    FFATGeometry gw = g;
+    if (bulk) gw.tree_cap = CW;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < runs; r += waves_total) {
         const uint32_t head = long_heads[r];
         const uint32_t slot = sslot[head];
-        FFATKeyState<R> st = states[slot];  // lane 0's copy is the live one
+        FFATKeyState<R> st = states[slot];  // bulk: identical in every lane; otherwise lane 0's copy is the live one
         R* gtree = trees + (size_t)slot * 2 * g.tree_cap;
-        R* tree = gtree;
-        if (lay.tree_nodes != 0) {
+        if (bulk) {
+            // import the panes a future window can still need
+            const uint64_t lo = st.panes > g.win_panes ? st.panes - g.win_panes : 0;
+            for (uint64_t idx = lo + lane; idx < st.panes; idx += WAVE)
+                ltree[CW + (uint32_t)(idx & (CW - 1))] = gtree[g.tree_cap + (uint32_t)(idx & (g.tree_cap - 1))];
+            wave_sync_lds();
+            fat_rebuild_wave(ltree, CW, comb);
+        } else if (lay.tree_nodes != 0) {
             for (uint32_t k = lane; k < 2 * g.tree_cap; k += WAVE) ltree[k] = gtree[k];
-            tree = ltree;
         }
         R* gacc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
         uint8_t* gused = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
-        R* acc = gacc;
-        uint8_t* used = gused;
-        if (g.is_tb && lay.acc_slots != 0) {
+        const bool acc_staged = g.is_tb && lay.acc_slots != 0;
+        if (acc_staged) {
             for (uint32_t k = lane; k < g.acc_cap; k += WAVE) {
                 lacc[k] = gacc[k];
                 lused[k] = gused[k];
             }
-            acc = lacc;
-            used = lused;
         }
+        wave_sync_lds();
         // software pipeline: chunk c+1 is loaded into registers before chunk c is reduced
         uint32_t j = head + lane;
         bool ok = (j < n) && (sslot[j] == slot);
@@ -399,9 +458,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 if (nok) nreg = data[sidx[j]];
             }
             // 2. segment index = number of boundaries at or before this lane
-            const uint32_t lo = (uint32_t)(segkey & 0xffffffffu), hi = (uint32_t)(segkey >> 32);
-            const uint32_t plo = (uint32_t)__shfl_up((int)lo, 1, WAVE), phi = (uint32_t)__shfl_up((int)hi, 1, WAVE);
-            const bool boundary = ok && (lane == 0 || plo != lo || phi != hi);
+            const uint32_t lo32 = (uint32_t)(segkey & 0xffffffffu), hi32 = (uint32_t)(segkey >> 32);
+            const uint32_t plo = (uint32_t)__shfl_up((int)lo32, 1, WAVE), phi = (uint32_t)__shfl_up((int)hi32, 1, WAVE);
+            const uint64_t prevkey = ((uint64_t)phi << 32) | plo;
+            const bool boundary = ok && (lane == 0 || prevkey != segkey);
             const unsigned long long bmask = __ballot(boundary);
             const unsigned long long upto_me = bmask & (lanemask_lt() | (1ull << lane));
             const int seg = __popcll(upto_me) - 1;
@@ -416,55 +476,137 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     val = tmp;
                 }
             }
-            // 4. the last lane of each segment publishes its aggregate
             const bool tail = ok && ((lane + 1 == (int)cnt) || ((bmask >> (lane + 1)) & 1ull));
-            if (tail) {
-                const int first = 63 - __builtin_clzll(upto_me);  // lane of my segment's boundary
-                segs[seg].agg = val;
-                segs[seg].len = (uint32_t)(lane - first + 1);
-            }
             const uint32_t n_segs = (uint32_t)__popcll(bmask);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // 5. sequential part: one step per segment
-            if (lane == 0) {
-                // one copy of the loop per staging combination, so that the compiler knows which pointers
-                // are LDS (ds_* instructions) and which are global instead of emitting flat accesses
-                auto fold_all = [&](R* tr, R* ac, uint8_t* us) {
-                    for (uint32_t u = 0; u < n_segs; u++) ffat_fold(st, tr, ac, us, g, segs[u].agg, segs[u].len, comb, emit, ctr);
-                };
-                const bool acc_staged = g.is_tb && lay.acc_slots != 0;
-                if (lay.tree_nodes != 0 && acc_staged)
-                    fold_all(ltree, lacc, lused);
-                else if (lay.tree_nodes != 0)
-                    fold_all(ltree, gacc, gused);
-                else if (acc_staged)
-                    fold_all(gtree, lacc, lused);
-                else
-                    fold_all(gtree, gacc, gused);
+            // 4. can the whole chunk be handled in bulk?
+            bool fast = bulk && cnt > 0;
+            uint64_t q_first = 0, q_last = 0;
+            if (fast && g.is_tb) {
+                q_first = ((uint64_t)(uint32_t)__shfl((int)hi32, 0, WAVE) << 32) | (uint32_t)__shfl((int)lo32, 0, WAVE);
+                q_last = ((uint64_t)(uint32_t)__shfl((int)hi32, (int)cnt - 1, WAVE) << 32) | (uint32_t)__shfl((int)lo32, (int)cnt - 1, WAVE);
+                const bool disorder = __ballot(ok && lane > 0 && segkey < prevkey) != 0;
+                fast = g.delay == 0 && !disorder && q_first >= st.last_quantum && q_last - st.last_quantum <= (uint64_t)WAVE;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // 6. the windows fired by this chunk leave together
+            if (fast) {
+                const auto key = wave_bcast(cf_key(val), 0);
+                const uint64_t P = st.panes;
+                uint32_t m;        // panes completed by this chunk
+                R open_val = val;  // value of my segment's pane, with what was already open folded in
+                if (!g.is_tb) {
+                    const uint32_t total = pc0 + cnt;
+                    m = (uint32_t)(total / g.pane_len);
+                    if (tail) {
+                        if (seg == 0 && pc0 > 0) fat_combine(comb, st.partial, val, open_val);
+                        if ((uint32_t)seg < m) ltree[CW + (uint32_t)((P + (uint64_t)seg) & (CW - 1))] = open_val;
+                    }
+                    const uint32_t rem = (uint32_t)(total % g.pane_len);
+                    const R last_val = wave_bcast(open_val, (int)cnt - 1);  // the last segment: the new open pane when rem > 0
+                    st.pcount = rem;
+                    if (rem > 0) st.partial = last_val;
+                } else {
+                    const uint64_t Lq = st.last_quantum;
+                    m = (uint32_t)(q_last - Lq);
+                    const uint32_t amask = g.acc_cap - 1;
+                    const bool open_used = lused[(uint32_t)(Lq & amask)] != 0;
+                    // every completed quantum starts as an empty pane ...
+                    if ((uint32_t)lane < m) {
+                        R e{};
+                        if (lane == 0 && open_used) e = lacc[(uint32_t)(Lq & amask)];  // ... except the one that was already open
+                        e.setControlFields(key, Lq + (uint64_t)lane, (Lq + (uint64_t)lane + 1) * g.pane_len - 1);
+                        ltree[CW + (uint32_t)((P + (uint64_t)lane) & (CW - 1))] = e;
+                    }
+                    wave_sync_lds();
+                    // ... and the segments overwrite theirs
+                    if (tail) {
+                        const uint32_t x = (uint32_t)(segkey - Lq);
+                        if (x == 0 && open_used) fat_combine(comb, lacc[(uint32_t)(Lq & amask)], val, open_val);
+                        if (x < m) {
+                            R v = open_val;
+                            v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
+                            ltree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
+                        }
+                    }
+                    const R last_val = wave_bcast(open_val, (int)cnt - 1);  // quantum q_last stays open
+                    wave_sync_lds();
+                    if (lane == 0) {
+                        for (uint32_t a = 0; a < g.acc_cap; a++) lused[a] = 0;
+                        lacc[(uint32_t)(q_last & amask)] = last_val;
+                        lused[(uint32_t)(q_last & amask)] = 1;
+                    }
+                    st.last_quantum = q_last;
+                    if (q_last + 1 > st.max_quantum) st.max_quantum = q_last + 1;
+                }
+                st.seen = 1;
+                wave_sync_lds();
+                if (m > 0) {
+                    fat_rebuild_wave(ltree, CW, comb);
+                    // windows fired by the chunk: k in [next_lwid, k_end), window k = panes [k*slide, k*slide + win)
+                    const uint64_t Pn = P + m;
+                    const uint64_t k_end = Pn >= g.win_panes ? (Pn - g.win_panes) / g.slide_panes + 1 : 0;
+                    const uint32_t nf = k_end > st.next_lwid ? (uint32_t)(k_end - st.next_lwid) : 0;  // <= m <= 64
+                    if ((uint32_t)lane < nf) {
+                        const uint64_t k = st.next_lwid + (uint64_t)lane;
+                        R res;
+                        fat_query_circular(ltree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
+                        res.setControlFields(key, k, cf_ts(res));
+                        emit.buf[lane] = res;
+                    }
+                    emit.n = nf;
+                    if (k_end > st.next_lwid) st.next_lwid = k_end;
+                    st.panes = Pn;
+                    wave_sync_lds();
+                }
+            } else {
+                // sequential rules, one step per segment, by lane 0
+                if (tail) {
+                    const int first = 63 - __builtin_clzll(upto_me);  // lane of my segment's boundary
+                    segs[seg].agg = val;
+                    segs[seg].len = (uint32_t)(lane - first + 1);
+                }
+                wave_sync_lds();
+                if (lane == 0) {
+                    // one copy of the loop per staging combination, so that the compiler knows which pointers
+                    // are LDS (ds_* instructions) and which are global instead of emitting flat accesses
+                    auto fold_all = [&](R* tr, R* ac, uint8_t* us, const FFATGeometry& geo) {
+                        for (uint32_t u = 0; u < n_segs; u++) ffat_fold(st, tr, ac, us, geo, segs[u].agg, segs[u].len, comb, emit, ctr);
+                    };
+                    if (lay.tree_nodes != 0 && acc_staged)
+                        fold_all(ltree, lacc, lused, gw);
+                    else if (lay.tree_nodes != 0)
+                        fold_all(ltree, gacc, gused, gw);
+                    else if (acc_staged)
+                        fold_all(gtree, lacc, lused, g);
+                    else
+                        fold_all(gtree, gacc, gused, g);
+                }
+                wave_sync_lds();
+                if (bulk) st = wave_bcast(st, 0);  // the bulk path keeps the state identical in every lane
+            }
+            // 5. the windows fired by this chunk leave together
             emit.flush_wave();
+            wave_sync_lds();
             if (cnt < WAVE) break;
             reg = nreg;
             ok = nok;
         }
-        if (lay.tree_nodes != 0) {
+        if (bulk) {
+            // export the panes a future window (or the end-of-stream flush) can still need, rebuild the key's tree
+            const uint64_t lo = st.panes > g.win_panes ? st.panes - g.win_panes : 0;
+            for (uint64_t idx = lo + lane; idx < st.panes; idx += WAVE)
+                gtree[g.tree_cap + (uint32_t)(idx & (g.tree_cap - 1))] = ltree[CW + (uint32_t)(idx & (CW - 1))];
+            wave_sync_lds();
+            fat_rebuild_wave(gtree, g.tree_cap, comb);
+        } else if (lay.tree_nodes != 0) {
             for (uint32_t k = lane; k < 2 * g.tree_cap; k += WAVE) gtree[k] = ltree[k];
         }
-        if (g.is_tb && lay.acc_slots != 0) {
+        if (acc_staged) {
             for (uint32_t k = lane; k < g.acc_cap; k += WAVE) {
                 gacc[k] = lacc[k];
                 gused[k] = lused[k];
             }
         }
         if (lane == 0) states[slot] = st;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
     }
 }
 
@@ -588,7 +730,7 @@ public:
         WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, sizeof(uint32_t), init.get()));
         // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
         // (60 KB of dynamic LDS per block of 4 waves)
-        long_layout_ = FFATLongLayout<R>::choose(g_.tree_cap, g_.acc_cap, g_.is_tb != 0, (60 * 1024) / (BLOCK_THREADS / WAVE));
+        long_layout_ = FFATLongLayout<R>::choose(g_, (60 * 1024) / (BLOCK_THREADS / WAVE));
         long_lds_bytes_ = (BLOCK_THREADS / WAVE) * long_layout_.wave_bytes();
         if (long_lds_bytes_ > 64 * 1024) failwith("Key_FFAT_GPU: result type too large for the LDS staging buffers");
         // the engine's kernels run on another stream: wait for the initialisation here
@@ -715,7 +857,7 @@ private:
     DeviceBuffer<uint32_t> slot_, idx_;
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;
-    FFATLongLayout<R> long_layout_{0, 0};
+    FFATLongLayout<R> long_layout_{0, 0, 0};
     // hipGraph cache
     struct GraphKey {
         const void* in;
