@@ -178,3 +178,65 @@ def test_key_ffat_with_hip_graph_replay(ext, monkeypatch):
     assert len(got) == len(exp)
     for k, (s, ts) in exp.items():
         assert got[k][0] == pytest.approx(s, abs=1e-9) and got[k][1] == ts
+
+
+# ---- the wave-per-run paths (few keys: long runs of one key inside a batch) --------------------------------------
+
+@pytest.mark.parametrize("n,n_keys,win,slide,batch,mode", [
+    (40000, 1, 12, 4, 4096, 1),     # pane = 4 tuples, bulk path, newest value wins
+    (40000, 3, 9, 3, 2048, 2),      # oldest value wins
+    (30000, 2, 7, 1, 1000, 1),      # pane = 1 tuple: 64 panes per chunk; batch not a multiple of the wave
+    (50000, 5, 192, 3, 8192, 1),    # 64 panes per window: the largest window the bulk path takes
+    (30000, 2, 300, 4, 4096, 2),    # 75 panes per window: staged tree, sequential per segment
+    (20000, 4, 1000, 999, 4096, 0), # pane = 1 tuple, 1000 panes per window
+])
+def test_key_ffat_long_runs_keep_order(ext, n, n_keys, win, slide, batch, mode):
+    t, vals = make_stream(n, n_keys, seed=n + win + mode)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, False, 16, batch, 4 * batch, mode)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0
+    got = unpack(res)
+    for key in np.unique(t[:, 0]):
+        v = vals[t[:, 0] == key]
+        lw = 0
+        while lw * slide < len(v):
+            w = v[lw * slide:lw * slide + win]
+            exp = w.sum() if mode == 0 else (w[-1] if mode == 1 else w[0])
+            assert got[(int(key), lw)][0] == pytest.approx(exp, abs=1e-9), (key, lw)
+            lw += 1
+    assert len(got) == sum(math.ceil((t[:, 0] == k).sum() / slide) for k in np.unique(t[:, 0]))
+
+
+def bursty_stream(n, n_keys, seed, gap_every, gap_len, disorder):
+    """Per-key timestamps that advance by 1, jump by gap_len every gap_every tuples, with bounded local disorder."""
+    rng = np.random.default_rng(seed)
+    t, vals = make_stream(n, n_keys, seed)
+    ts = np.zeros(n, dtype=np.int64)
+    clock = {}
+    count = {}
+    for i in range(n):
+        k = t[i, 0]
+        c = count.get(k, 0)
+        clock[k] = clock.get(k, 0) + (gap_len if c and c % gap_every == 0 else 1)
+        count[k] = c + 1
+        ts[i] = clock[k]
+    if disorder:
+        ts = ts + rng.integers(0, disorder + 1, n)  # arrival order no longer matches timestamp order
+    t[:, 2] = ts
+    return t, vals
+
+
+@pytest.mark.parametrize("n,n_keys,win,slide,batch,gap_every,gap_len,disorder,delay", [
+    (30000, 2, 40, 10, 4096, 500, 35, 0, 0),       # short silences: empty panes inside bulk chunks
+    (30000, 3, 40, 10, 2048, 700, 5000, 0, 0),     # long silences: more than 64 empty panes, sequential fallback
+    (20000, 2, 60, 20, 4096, 10**9, 1, 7, 16),     # out-of-order arrivals within the triggering delay
+    (20000, 1, 8, 2, 512, 300, 90, 0, 0),
+])
+def test_key_ffat_time_based_long_runs(ext, n, n_keys, win, slide, batch, gap_every, gap_len, disorder, delay):
+    t, vals = bursty_stream(n, n_keys, seed=n + win, gap_every=gap_every, gap_len=gap_len, disorder=disorder)
+    res, ctr = ext.key_ffat_run(t, win, slide, delay, True, 16, batch, 1 << 18)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    got = unpack(res)
+    exp = oracle_tb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, s in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9), k

@@ -141,7 +141,7 @@ __device__ __forceinline__ void ffat_complete_pane(FFATKeyState<R>& st, R* tree,
 
 constexpr int FFAT_PREFETCH = 4;
 // runs of at least this many tuples are left to the wave-per-run kernel
-constexpr uint32_t FFAT_LONG_RUN = 32;
+constexpr uint32_t FFAT_LONG_RUN = 12;
 
 // `lifted` is the aggregate of `len` consecutive tuples of a key that all belong to the same pane
 // (CB) / quantum (TB): fold it into the open pane / quantum and complete what it closes.  With
