@@ -298,14 +298,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-// Long runs: one wave64 per run, exploiting the associativity of the combine.  The 64 lanes gather
-// and LIFT the next 64 tuples of the run together; lanes whose tuples fall in the same pane (CB) /
-// quantum (TB) form a segment and a segmented wave scan (6 shuffle + combine steps, order
-// preserving, so the combine needs not be commutative) leaves each segment's aggregate in its last
-// lane.  Only the per-SEGMENT step (fold into the open pane, complete panes, fire windows) is
-// sequential, in lane 0.  When it fits, the key's tree is staged in LDS for the whole run, so
-// pane inserts and window queries never wait on HBM.  Dynamic LDS per wave: 64 segment slots +
-// `lds_nodes` tree nodes.
+// aggregate of one segment (tuples of a chunk that fall in the same pane / quantum), staged in LDS for
+// the sequential per-segment fold of the long-run kernel
 template <typename R>
 struct FFATSegment {
     R agg;
