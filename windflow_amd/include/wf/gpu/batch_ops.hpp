@@ -180,6 +180,8 @@ inline std::function<rt::Node*(edge_kind_t)> batch_adapter_factory(size_t produc
 // (+ RuntimeContext& as last argument).  false = end of stream.
 template <typename tuple_t, typename F>
 class Batch_Source_Node : public Replica_Base {
+    static_assert(std::is_trivially_copyable_v<tuple_t>, "batched tuples are shipped as raw bytes: they must be trivially copyable");
+
 public:
     Batch_Source_Node(F func, size_t batch_len, size_t slabs, int device, std::string name, size_t par, size_t idx,
                       meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
@@ -313,6 +315,8 @@ private:
 // ---- base of the batched GPU replicas ----------------------------------------
 template <typename in_t>
 class GPU_Replica : public Replica_Base {
+    static_assert(std::is_trivially_copyable_v<in_t>, "tuples processed on the GPU travel in raw batches: they must be trivially copyable");
+
 public:
     GPU_Replica(GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx, meta::closing_func_t closing,
                 std::shared_ptr<StatsHub> hub, bool is_win = false)

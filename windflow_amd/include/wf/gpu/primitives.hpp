@@ -282,9 +282,127 @@ __global__ void __launch_bounds__(BLOCK_THREADS) radix_bin_scan_kernel(uint32_t*
     if (threadIdx.x == 0) bin_totals[blockIdx.x] = s_carry;
 }
 
+// ---- wide digits: 11 bits per pass (2048 bins) -------------------------------------------------
+// Every pass costs three launches whose duration is latency, not bandwidth, for the batch sizes of a
+// streaming pipeline; slots of a 2^18-entry key table need three 8-bit passes but only two 11-bit
+// ones.  2048 bins do not fit the (round, wave) counter matrix of the 8-bit scatter, so here a tile
+// is blocked by wave (wave w owns elements [w*512, (w+1)*512) of the tile) and each wave keeps ONE
+// running counter per digit across its 8 rounds: order (wave, round, lane) is the input order, so the
+// pass is stable.
+constexpr int RSW_BITS = 11;
+constexpr int RSW_BINS = 1 << RSW_BITS;
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    radix_hist_wide_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/) {
+    __shared__ uint32_t s_hist[RSW_BINS];
+    const uint32_t n = *n_ptr;
+    const uint32_t tile = blockIdx.x;
+    for (int b = threadIdx.x; b < RSW_BINS; b += BLOCK_THREADS) s_hist[b] = 0;
+    __syncthreads();
+    const uint32_t base = tile * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = base + k * BLOCK_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & (RSW_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < RSW_BINS; b += BLOCK_THREADS) hist[(size_t)b * n_tiles + tile] = s_hist[b];
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    radix_scatter_wide_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
+                              uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
+                              const uint32_t* bin_totals /*[bin]*/) {
+    constexpr int NW = BLOCK_THREADS / WAVE;
+    constexpr int PER_THREAD = RSW_BINS / BLOCK_THREADS;  // bins whose global base a thread computes
+    __shared__ uint32_t s_cnt[NW][RSW_BINS];               // per-wave running digit counters, then offsets (32 KiB)
+    __shared__ uint32_t s_bin_base[RSW_BINS];
+    __shared__ uint32_t s_wsum[NW];
+    const int lane = lane_id(), wave = wave_id();
+    {
+        // exclusive scan of the 2048 bin totals: 8 consecutive bins per thread
+        uint32_t local[PER_THREAD];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            local[q] = bin_totals[threadIdx.x * PER_THREAD + q];
+            sum += local[q];
+        }
+        const uint32_t inc = wave_inclusive_scan(sum);
+        if (lane == WAVE - 1) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = inc - sum;
+        for (int w = 0; w < wave; w++) off += s_wsum[w];
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            s_bin_base[threadIdx.x * PER_THREAD + q] = off;
+            off += local[q];
+        }
+    }
+    for (int b = threadIdx.x; b < RSW_BINS; b += BLOCK_THREADS) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) s_cnt[w][b] = 0;
+    }
+    __syncthreads();
+    const uint32_t n = *n_ptr;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * RS_TILE + (uint32_t)wave * (RS_ITEMS * WAVE);
+    uint32_t k_[RS_ITEMS], v_[RS_ITEMS], rank[RS_ITEMS];
+    bool ok[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t i = base + k * WAVE + lane;
+        ok[k] = i < n;
+        k_[k] = ok[k] ? keys_in[i] : 0xffffffffu;
+        v_[k] = ok[k] ? vals_in[i] : 0u;
+        const uint32_t digit = (k_[k] >> shift) & (RSW_BINS - 1);
+        // lanes of this wave holding the same digit (match-any with 11 ballots)
+        unsigned long long m = __ballot(ok[k]);
+#pragma unroll
+        for (int b = 0; b < RSW_BITS; b++) {
+            const unsigned long long bal = __ballot((digit >> b) & 1);
+            m &= ((digit >> b) & 1) ? bal : ~bal;
+        }
+        const uint32_t in_match = (uint32_t)__popcll(m & lanemask_lt());
+        uint32_t prev = 0;
+        if (ok[k] && in_match == 0) {  // the first lane of every group advances the wave's counter of that digit
+            prev = s_cnt[wave][digit];
+            s_cnt[wave][digit] = prev + (uint32_t)__popcll(m);
+        }
+        const int leader = ok[k] ? (int)__builtin_ctzll(m) : lane;
+        prev = (uint32_t)__shfl((int)prev, leader, WAVE);
+        rank[k] = prev + in_match;
+        // the next round of this wave must see the counters written by this one
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    // per digit: exclusive prefix over the waves + global base of the digit + offset of this tile inside the digit
+    for (int d = threadIdx.x; d < RSW_BINS; d += BLOCK_THREADS) {
+        uint32_t run = s_bin_base[d] + hist_scanned[(size_t)d * n_tiles + tile];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        if (ok[k]) {
+            const uint32_t digit = (k_[k] >> shift) & (RSW_BINS - 1);
+            const uint32_t dst = s_cnt[wave][digit] + rank[k];
+            keys_out[dst] = k_[k];
+            vals_out[dst] = v_[k];
+        }
+    }
+}
+
 // Workspace + driver for sorting up to `capacity` pairs.  `bits` = number of
-// significant key bits (passes = ceil(bits/8)).  n is read from device memory so a
-// data-dependent count never has to come back to the host.
+// significant key bits.  n is read from device memory so a data-dependent count
+// never has to come back to the host.
 class RadixSorter {
 public:
     void reserve(size_t capacity) {
@@ -293,13 +411,22 @@ public:
         tiles_ = (capacity + RS_TILE - 1) / RS_TILE;
         keys_tmp_.resize(capacity);
         vals_tmp_.resize(capacity);
-        hist_.resize((size_t)RS_BINS * tiles_);
-        bin_totals_.resize(RS_BINS);
+        hist_.resize((size_t)RSW_BINS * tiles_);
+        bin_totals_.resize(RSW_BINS);
     }
     struct Sorted {
         uint32_t* keys;
         uint32_t* vals;
     };
+    // digit width of the passes: 11-bit digits when that saves a pass, 8-bit ones otherwise
+    static int digit_bits(int bits) {
+        const int p8 = std::max(1, (bits + 7) / 8), p11 = std::max(1, (bits + RSW_BITS - 1) / RSW_BITS);
+        return p11 < p8 ? RSW_BITS : 8;
+    }
+    static int passes(int bits) {
+        const int d = digit_bits(bits);
+        return std::max(1, (bits + d - 1) / d);
+    }
     // sorts the pairs (ping-pong between the caller's arrays and internal buffers) and
     // returns where the sorted pairs live; n_upper bounds the grid, the exact count is
     // read from device memory
@@ -311,20 +438,26 @@ public:
         if (tiles == 0) return {kin, vin};
         uint32_t* kout = keys_tmp_.data();
         uint32_t* vout = vals_tmp_.data();
-        int passes = (bits + 7) / 8;
-        if (passes < 1) passes = 1;
-        for (int p = 0; p < passes; p++) {
-            const int shift = 8 * p;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
-            hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
-                               hist_.data(), bin_totals_.data());
+        const int d = digit_bits(bits), n_pass = passes(bits);
+        for (int p = 0; p < n_pass; p++) {
+            const int shift = d * p;
+            if (d == 8) {
+                hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
+                hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
+                                   hist_.data(), bin_totals_.data());
+            } else {
+                hipLaunchKernelGGL(radix_hist_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
+                hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RSW_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                hipLaunchKernelGGL(radix_scatter_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
+                                   hist_.data(), bin_totals_.data());
+            }
             std::swap(kin, kout);
             std::swap(vin, vout);
         }
         return {kin, vin};
     }
-    int kernels_per_sort(int bits) const { return 3 * std::max(1, (bits + 7) / 8); }
+    int kernels_per_sort(int bits) const { return 3 * passes(bits); }
 
 private:
     size_t cap_ = 0, tiles_ = 0;
