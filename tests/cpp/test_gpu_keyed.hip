@@ -40,6 +40,13 @@ struct EveryThird {
         (void)t;
     }
 };
+struct EveryThirdOut {
+    __host__ __device__ void operator()(const output_t&, bool& keep, char* state, size_t) const {
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(state);
+        keep = (*cnt % 3) == 0;
+        (*cnt)++;
+    }
+};
 struct Lift_GPU {
     __host__ __device__ void operator()(const tuple_t& t, output_t& r) const { r.value = t.value; }
 };
@@ -195,7 +202,8 @@ int main(int argc, char** argv) {
         auto srcB = BatchSource_Builder(Gen(n, keys)).withName("srcB").withParallelism(1).withBatch(batch).build_unique();
         MultiPipe& a = g.add_source(*srcA);
         MultiPipe& b = g.add_source(*srcB);
-        auto mapA = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value * 2; }).withName("dbl").withParallelism(p1).build_unique();
+        auto mapA = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value * 2; }).withName("dbl").withParallelism(p1)
+                        .withGPUPlacement({0, 0, 0}).build_unique();  // placement per replica (all on the one GPU of the test box)
         auto mapB = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value + 100; }).withName("plus").withParallelism(p2).build_unique();
         a.add(*mapA);
         b.add(*mapB);
@@ -238,6 +246,32 @@ int main(int argc, char** argv) {
         const bool ok = neg_sum == e_neg_sum && neg_cnt == e_neg_cnt && pos_sum == e_pos_sum && pos_cnt == e_pos_cnt;
         cout << "D par=" << p1 << "," << p2 << " batch=" << batch << " neg " << neg_sum << "/" << neg_cnt << " pos " << pos_sum << "/" << pos_cnt
              << (ok ? "  OK" : "  FAILED") << endl;
+        failures += !ok;
+    }
+    // ---- E (only with 2+ GPUs): scenario B with the replicas of the two keyed operators placed on different GPUs; the
+    //      sub-batches of the device KeyBy cross GPUs with peer copies ----
+    if (gpu::device_count() >= 2) {
+        const size_t batch = 1024;
+        PipeGraph g("keyed_e", Mode::DEFAULT);
+        auto src = BatchSource_Builder(Gen(n, keys)).withParallelism(1).withBatch(batch).build_unique();
+        MultiPipe& mp = g.add_source(*src);
+        auto map = MapGPU_Builder(RunningSumOut()).withName("kmap").withParallelism(2).withScratchpad(8).withMaxKeys(keys)
+                       .withGPUPlacement({0, 1}).build_unique();
+        mp.add(*map);
+        auto fil = FilterGPU_Builder(EveryThirdOut()).withName("kfilter").withParallelism(2).withScratchpad(8).withMaxKeys(keys)
+                       .withGPUPlacement({1, 0}).build_unique();
+        mp.add(*fil);
+        long sum = 0, cnt = 0;
+        Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
+                        if (o) {
+                            sum += o->value;
+                            cnt++;
+                        }
+                    }).withParallelism(1).build();
+        mp.add_sink(sink);
+        g.run();
+        const bool ok = (sum == exp_b_sum && cnt == exp_b_cnt);
+        cout << "E two GPUs sum " << sum << " cnt " << cnt << (ok ? "  OK" : "  FAILED") << endl;
         failures += !ok;
     }
     (void)EveryThird{};

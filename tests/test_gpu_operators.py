@@ -50,4 +50,4 @@ def run_keyed_cpp(args, timeout=110):
 def test_keyed_gpu_operators_and_device_keyby(n, keys):
     """Keyed Map_GPU / Filter_GPU (per-key scratchpad state) and Key_FFAT_GPU behind the device KeyBy emitter."""
     out = run_keyed_cpp([n, keys, 2])
-    assert out.count("  OK") == 8 and "FAILED" not in out  # scenarios A, B, C, D x 2 runs
+    assert out.count("  OK") >= 8 and "FAILED" not in out  # scenarios A, B, C, D x 2 runs (+ E on a box with 2+ GPUs)

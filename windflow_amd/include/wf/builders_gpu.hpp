@@ -31,6 +31,12 @@ public:
         cfg_.n_thread_block = n_thread_block;
         return this->self();
     }
+    // replica i of the operator runs on gpu_ids[i % gpu_ids.size()] (one process driving several GPUs)
+    Derived& withGPUPlacement(std::vector<int> gpu_ids) {
+        cfg_.gpu_ids = std::move(gpu_ids);
+        if (!cfg_.gpu_ids.empty()) cfg_.gpu_id = cfg_.gpu_ids[0];
+        return this->self();
+    }
     Derived& withGPUThreadsPerBlock(size_t n) {
         cfg_.n_thread_block = n;
         return this->self();

@@ -27,6 +27,10 @@ namespace wf {
 
 struct GPUConfig {
     int gpu_id = 0;
+    // placement per replica: replica i runs on gpu_ids[i % size]; empty = every replica on gpu_id.
+    // A device batch produced on another GPU is pulled over with a peer copy (xGMI) by the consuming replica.
+    std::vector<int> gpu_ids;
+    int device_for(size_t replica) const { return gpu_ids.empty() ? gpu_id : gpu_ids[replica % gpu_ids.size()]; }
     size_t batch_len = 65536;       // tuples per batch when the operator builds batches itself
     size_t n_thread_block = DEFAULT_GPU_THREADS_PER_BLOCK;
     size_t pool_slabs = 6;          // slabs per pool = batches in flight (back-pressure)
@@ -320,7 +324,9 @@ class GPU_Replica : public Replica_Base {
 public:
     GPU_Replica(GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx, meta::closing_func_t closing,
                 std::shared_ptr<StatsHub> hub, bool is_win = false)
-        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), is_win, true), cfg_(cfg), in_kind_(in_kind) {}
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), is_win, true), cfg_(cfg), in_kind_(in_kind) {
+        cfg_.gpu_id = cfg.device_for(idx);
+    }
 
     void svc_init() override {
         Replica_Base::svc_init();
@@ -348,6 +354,7 @@ public:
                 break;
             case EDGE_DEVICE_BATCH: {
                 gpu::Batch* d = static_cast<gpu::Batch*>(msg);
+                if (d->device != cfg_.gpu_id) d = pull_from_peer(d);
                 d->ready.wait_on(*stream_);
                 gpu::TraceRange tr("wf:enqueue_kernels");
                 process_device(d);
@@ -403,6 +410,28 @@ private:
             staging_pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, cfg_.gpu_id, sizeof(in_t), cfg_.batch_len, cfg_.pool_slabs));
         staging_ = staging_pool_->acquire_host();
         staging_->host_hdr.created_ns = current_time_nsecs();
+    }
+    // a device batch that lives on another GPU: copy it into a slab of this replica's device (peer copy over xGMI)
+    gpu::Batch* pull_from_peer(gpu::Batch* d) {
+        gpu::TraceRange tr("wf:peer_copy");
+        if (!d->count_on_host) {  // the copy is sized on the host
+            d->ready.host_sync();
+            d->host_hdr.count = *d->count_mirror;
+            d->count_on_host = true;
+        }
+        if (!dev_in_pool_)
+            dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), d->capacity, cfg_.pool_slabs));
+        gpu::Batch* mine = dev_in_pool_->acquire(stream());
+        d->ready.wait_on(stream());
+        mine->host_hdr = d->host_hdr;
+        mine->count_on_host = true;
+        WF_HIP_CHECK(hipMemcpyAsync(mine->slab, &mine->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, stream()));
+        const size_t bytes = (size_t)d->host_hdr.count * sizeof(in_t);
+        if (bytes > 0)
+            WF_HIP_CHECK(hipMemcpyPeerAsync(mine->template data<in_t>(), cfg_.gpu_id, d->template data<in_t>(), d->device, bytes, stream()));
+        d->release(stream());
+        mine->ready.record(stream());
+        return mine;
     }
     // host batch -> device batch (async), then run the operator on it
     void ship(gpu::Batch* h) {

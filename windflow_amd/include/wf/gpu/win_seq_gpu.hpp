@@ -65,6 +65,7 @@ public:
         : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), true, true), func_(func), p_(p), cfg_g_(cfg) {
         if (p_.win_len == 0 || p_.slide_len == 0) fatal_error("window length or slide cannot be zero");
         if (cfg_g_.batch_len == 0) fatal_error("batch length cannot be zero");
+        cfg_g_.gpu_id = cfg.device_for(idx);
         set_io_bytes(sizeof(tuple_t), sizeof(result_t));
     }
 
