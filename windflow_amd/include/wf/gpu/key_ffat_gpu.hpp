@@ -538,14 +538,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     const uint64_t Pn = P + m;
                     const uint64_t k_end = Pn >= g.win_panes ? (Pn - g.win_panes) / g.slide_panes + 1 : 0;
                     const uint32_t nf = k_end > st.next_lwid ? (uint32_t)(k_end - st.next_lwid) : 0;  // <= m <= 64
+                    // results are parked in LDS and leave with one atomic when the 64 slots are full (or at the end
+                    // of the run): a returning global atomic per chunk would dominate chunks that fire few windows
+                    if (emit.n + nf > (uint32_t)WAVE) {
+                        emit.flush_wave();
+                        wave_sync_lds();
+                    }
                     if ((uint32_t)lane < nf) {
                         const uint64_t k = st.next_lwid + (uint64_t)lane;
                         R res;
                         fat_query_circular(ltree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
                         res.setControlFields(key, k, cf_ts(res));
-                        emit.buf[lane] = res;
+                        emit.buf[emit.n + (uint32_t)lane] = res;
                     }
-                    emit.n = nf;
+                    emit.n += nf;
                     if (k_end > st.next_lwid) st.next_lwid = k_end;
                     st.panes = Pn;
                     wave_sync_lds();
@@ -574,15 +580,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                         fold_all(gtree, gacc, gused, g);
                 }
                 wave_sync_lds();
-                if (bulk) st = wave_bcast(st, 0);  // the bulk path keeps the state identical in every lane
+                if (bulk) {  // the bulk path keeps the state (and the number of parked results) identical in every lane
+                    st = wave_bcast(st, 0);
+                    emit.n = (uint32_t)__shfl((int)emit.n, 0, WAVE);
+                } else {
+                    emit.flush_wave();
+                    wave_sync_lds();
+                }
             }
-            // 5. the windows fired by this chunk leave together
-            emit.flush_wave();
-            wave_sync_lds();
             if (cnt < WAVE) break;
             reg = nreg;
             ok = nok;
         }
+        emit.flush_wave();  // whatever the last chunks parked
+        wave_sync_lds();
         if (bulk) {
             // export the panes a future window (or the end-of-stream flush) can still need, rebuild the key's tree
             const uint64_t lo = st.panes > g.win_panes ? st.panes - g.win_panes : 0;
