@@ -91,6 +91,10 @@ static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector
     } else if (c.op == "kff") {
         auto b = KeyFFATGPU_Builder(Lift_GPU(), Comb_GPU());
         mp.add(*hold(set_windows(b, c).withName("kff_gpu").withParallelism(p1).withBatch(64 * batch).withMaxKeys(64).withOutputCapacity(1 << 17).build_ptr()));
+    } else if (c.op == "seqffat") {
+        auto b = WinSeqFFATGPU_Builder(Lift_GPU(), Comb_GPU());
+        mp.add(*hold(set_windows(b, c).withName("seqffat_gpu").withBatch(64 * batch).withMaxKeys(64).withOutputCapacity(1 << 17).withRebuild(false)
+                         .build_ptr()));
     } else if (c.op == "kf+pf") {
         auto b = PaneFarmGPU_Builder(Win_GPU(), win2_nic);
         auto* pf = hold(set_windows(b, c).withName("pf_inner").withParallelism(p2, p3).withBatch(batch).prepare4Nesting().build_ptr());

@@ -21,7 +21,7 @@ def run_gpu_cpp(args, timeout=110):
     return r.stdout
 
 
-GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "kf+pf", "wf+wmr"]
+GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "seqffat", "kf+pf", "wf+wmr"]
 
 
 @pytest.mark.parametrize("op", GPU_OPS)

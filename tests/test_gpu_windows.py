@@ -240,3 +240,29 @@ def test_key_ffat_time_based_long_runs(ext, n, n_keys, win, slide, batch, gap_ev
     assert len(res) == len(got) == len(exp)
     for k, s in exp.items():
         assert got[k][0] == pytest.approx(s, abs=1e-9), k
+
+
+@pytest.mark.parametrize("n_keys,batch", [(3, 2048), (400, 4096)])
+def test_key_ffat_skips_long_empty_stretches_when_asked(ext, n_keys, batch):
+    """skip_gaps: a key silent for much longer than a window does not emit one empty result per slide."""
+    win, slide, gap = 40, 10, 100_000
+    t, vals = bursty_stream(12000, n_keys, seed=3, gap_every=1500 if n_keys < 10 else 10, gap_len=gap, disorder=0)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, True, 1024, batch, 1 << 18, 0, True)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0
+    assert ctr["skipped_windows"] > 0
+    got = unpack(res)
+    # sparse oracle: only the windows that hold data are enumerated (the stream spans millions of windows)
+    q = math.gcd(win, slide)
+    with_data, total_windows = {}, 0
+    for key in np.unique(t[:, 0]):
+        m = t[:, 0] == key
+        for ts, v in zip(t[m, 2], vals[m]):
+            for lw in range(max(0, -(-(int(ts) - win + 1) // slide)), int(ts) // slide + 1):
+                with_data[(int(key), lw)] = with_data.get((int(key), lw), 0.0) + v
+        n_panes = int(t[m, 2].max()) // q + 1
+        total_windows += -(-n_panes // (slide // q))
+    # every window that holds data is there with the right value; what was skipped was empty
+    for k, s in with_data.items():
+        assert k in got and got[k][0] == pytest.approx(s, abs=1e-9), k
+    assert len(got) + ctr["skipped_windows"] == total_windows
+    assert len(got) < total_windows // 10

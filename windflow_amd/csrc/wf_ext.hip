@@ -194,7 +194,8 @@ struct CombByMode {
 };
 
 static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::array::forcecast> tuples, uint64_t win, uint64_t slide,
-                              uint64_t delay, bool time_based, size_t max_keys, size_t batch_len, size_t out_capacity, int comb_mode) {
+                              uint64_t delay, bool time_based, size_t max_keys, size_t batch_len, size_t out_capacity, int comb_mode,
+                              bool skip_gaps) {
     auto buf = tuples.request();
     if (buf.ndim != 2 || buf.shape[1] != 5) throw std::invalid_argument("tuples must be [n,5] int64");
     const size_t n = (size_t)buf.shape[0];
@@ -203,7 +204,7 @@ static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::arra
     gpu::Stream stream;
     if (out_capacity == 0) out_capacity = batch_len;
     gpu::KeyedFFATEngine<tuple_t, result_t, wfbench::LiftValue, CombByMode> engine(wfbench::LiftValue{}, CombByMode{comb_mode}, win, slide, delay,
-                                                                                    time_based ? TB : CB, max_keys, batch_len, out_capacity, 0, 3);
+                                                                                    time_based ? TB : CB, max_keys, batch_len, out_capacity, 0, 3, skip_gaps);
     gpu::BatchPool in_pool(gpu::MemKind::DEVICE, 0, sizeof(tuple_t), batch_len, 2);
     std::vector<result_t> results;
     uint64_t kernels = 0;
@@ -476,7 +477,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("map_scale_inplace", &map_scale_inplace, py::arg("tuples"), py::arg("n"), py::arg("factor"));
     m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
     m.def("key_ffat_run", &key_ffat_run, py::arg("tuples"), py::arg("win"), py::arg("slide"), py::arg("delay"), py::arg("time_based"),
-          py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0, py::arg("comb_mode") = 0);
+          py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0, py::arg("comb_mode") = 0, py::arg("skip_gaps") = false);
     m.def("radix_sort_pairs", &radix_sort_pairs, py::arg("keys"), py::arg("vals"), py::arg("n"), py::arg("bits"));
     m.def("exclusive_scan", &exclusive_scan, py::arg("inp"), py::arg("out"), py::arg("n"));
     py::class_<dist::Transport, std::shared_ptr<dist::Transport>>(m, "Transport")
