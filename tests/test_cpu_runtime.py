@@ -95,3 +95,10 @@ def test_runtime_tsan():
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + wfbuild.INCLUDE, src, "-o", exe, "-pthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, WF_QUIET="1"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_api_variants():
+    """Every functor signature accepted by the builders (plain / rich, Source loop mode, Filter modes, Sink forms,
+    window function flavours, closing functions, LocalStorage, custom KeyBy routing)."""
+    out = run_cpp("test_api_variants")
+    assert "ALL OK" in out and "FAILED" not in out

@@ -78,6 +78,7 @@ PROGRAMS = [
     ("tests/cpp/test_mp_windows.cpp", "tests/cpp/bin/test_mp_windows", False),
     ("tests/cpp/test_graphs.cpp", "tests/cpp/bin/test_graphs", False),
     ("tests/cpp/test_runtime.cpp", "tests/cpp/bin/test_runtime", False),
+    ("tests/cpp/test_api_variants.cpp", "tests/cpp/bin/test_api_variants", False),
     ("tests/cpp/test_mp_windows_gpu.hip", "tests/cpp/bin/test_mp_windows_gpu", True),
     ("tests/cpp/test_gpu_keyed.hip", "tests/cpp/bin/test_gpu_keyed", True),
     ("apps/ysb/ysb_kf.cpp", "apps/bin/ysb_kf", False),
