@@ -74,36 +74,36 @@ struct WinResult {
     }
 };
 
-// campaigns and their ads; ad ids are a fixed pseudo-random permutation of
-// [0, n_ads) so both a hash join (CPU) and a dense table join (GPU) are possible
+// campaigns and their ads.  Ad ids are a fixed permutation of [0, n_ads): ad(i) = (A*i + B) mod n_ads, so the
+// CPU versions can join through a hash map (as the reference does) and the GPU version can invert the permutation
+// arithmetically - no lookup table to replicate on every GPU.
 class Campaigns {
 public:
+    static constexpr uint64_t A = 7919, B = 123;
     explicit Campaigns(size_t n_campaigns = 100, size_t ads_per_campaign = 10) : n_cmp_(n_campaigns), per_(ads_per_campaign) {
-        const size_t n = n_cmp_ * per_;
+        const uint64_t n = n_cmp_ * per_;
         ads_.resize(n);
-        dense_.resize(n);
-        for (size_t i = 0; i < n; i++) ads_[i] = i;
-        uint64_t s = 0x9e3779b97f4a7c15ULL;
-        for (size_t i = n - 1; i > 0; i--) {  // Fisher-Yates with an LCG
-            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
-            std::swap(ads_[i], ads_[(s >> 33) % (i + 1)]);
-        }
-        for (size_t i = 0; i < n; i++) {
+        for (uint64_t i = 0; i < n; i++) {
+            ads_[i] = (A * i + B) % n;
             by_ad_[ads_[i]] = i / per_;
-            dense_[ads_[i]] = (uint32_t)(i / per_);
         }
+        if (by_ad_.size() != n) wf::fatal_error("Campaigns: the number of ads must be coprime with 7919");
+        for (uint64_t x = 1; x < n; x++)
+            if ((A % n) * x % n == 1) inv_a_ = x;
+        if (n == 1) inv_a_ = 0;
     }
     size_t n_campaigns() const { return n_cmp_; }
     size_t n_ads() const { return ads_.size(); }
+    size_t ads_per_campaign() const { return per_; }
     uint64_t ad(size_t i) const { return ads_[i % ads_.size()]; }
+    uint64_t inverse_multiplier() const { return inv_a_; }  // position of ad a = ((a + n - B % n) % n) * inverse_multiplier % n
     const std::unordered_map<uint64_t, uint64_t>& ad_to_campaign() const { return by_ad_; }
-    const std::vector<uint32_t>& dense_table() const { return dense_; }  // campaign of ad id a = dense[a]
 
 private:
     size_t n_cmp_, per_;
     std::vector<uint64_t> ads_;
     std::unordered_map<uint64_t, uint64_t> by_ad_;
-    std::vector<uint32_t> dense_;
+    uint64_t inv_a_ = 0;
 };
 
 // run-wide counters
@@ -228,13 +228,13 @@ private:
 
 struct Options {
     uint64_t seconds = 0, events = 0, period_us = 100;
-    size_t par1 = 1, par2 = 1, batch = 4096;
+    size_t par1 = 1, par2 = 1, batch = 4096, gpus = 1;
     bool ok = true;
 };
 inline Options parse(int argc, char** argv, const char* extra_usage = "") {
     Options o;
     int c;
-    while ((c = getopt(argc, argv, "l:e:p:n:m:b:")) != -1) {
+    while ((c = getopt(argc, argv, "l:e:p:n:m:b:g:")) != -1) {
         switch (c) {
             case 'l': o.seconds = std::strtoull(optarg, nullptr, 10); break;
             case 'e': o.events = std::strtoull(optarg, nullptr, 10); break;
@@ -242,6 +242,7 @@ inline Options parse(int argc, char** argv, const char* extra_usage = "") {
             case 'n': o.par1 = std::strtoull(optarg, nullptr, 10); break;
             case 'm': o.par2 = std::strtoull(optarg, nullptr, 10); break;
             case 'b': o.batch = std::strtoull(optarg, nullptr, 10); break;
+            case 'g': o.gpus = std::strtoull(optarg, nullptr, 10); break;
             default: o.ok = false;
         }
     }

@@ -16,13 +16,13 @@ struct ViewFilterGPU {
     __host__ __device__ bool operator()(const ysb::Event& e) const { return e.event_type == 0; }
 };
 struct JoinGPU {
-    const uint32_t* table;  // device memory: campaign of ad id a
-    uint32_t n_ads;
+    uint64_t n_ads, per_campaign, inv_a, b;  // inverse of the ad-id permutation (ysb::Campaigns)
     __host__ __device__ void operator()(const ysb::Event& e, ysb::Joined& j) const {
         j.ts = e.ts;
         j.seq = e.seq;
         j.ad_id = e.ad_id;
-        j.cmp_id = e.ad_id < n_ads ? table[e.ad_id] : 0xffffffffu;
+        const uint64_t pos = ((e.ad_id % n_ads + n_ads - b % n_ads) % n_ads) * inv_a % n_ads;
+        j.cmp_id = e.ad_id < n_ads ? pos / per_campaign : 0xffffffffull;
     }
 };
 struct CountWindowGPU {
@@ -35,16 +35,17 @@ struct CountWindowGPU {
 };
 
 int main(int argc, char** argv) {
-    ysb::Options o = ysb::parse(argc, argv, " [-b <device batch length>]");
+    ysb::Options o = ysb::parse(argc, argv, " [-b <device batch length>] [-g <GPUs to spread the replicas over>]");
     if (!o.ok) return 0;
-    if (gpu::device_count() < 1) {
-        std::cerr << "ysb_gpu needs a GPU" << std::endl;
+    if (gpu::device_count() < 1 || (size_t)gpu::device_count() < o.gpus) {
+        std::cerr << "ysb_gpu: not enough GPUs" << std::endl;
         return 3;
     }
+    // replica i of every GPU operator runs on GPU i % gpus (one process driving several GPUs: BASELINE config 5)
+    std::vector<int> placement;
+    for (size_t i = 0; i < std::max<size_t>(1, o.gpus); i++) placement.push_back((int)i);
     ysb::Campaigns campaigns;
     ysb::Metrics metrics;
-    gpu::DeviceBuffer<uint32_t> table(campaigns.n_ads());
-    WF_HIP_CHECK(hipMemcpy(table.data(), campaigns.dense_table().data(), campaigns.n_ads() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
     // DETERMINISTIC: the batch lanes keep their order and the window stage merges them by timestamp, so no
     // event is dropped as late when several sources run at different speeds
@@ -52,13 +53,14 @@ int main(int argc, char** argv) {
     auto source = BatchSource_Builder(ysb::EventSource(&campaigns, &metrics, o.seconds, o.events, o.period_us)).withName("ysb_source")
                       .withParallelism(o.par1).withBatch(o.batch).build_unique();
     MultiPipe& pipe = graph.add_source(*source);
-    auto filter = FilterGPU_Builder(ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(o.par1).build_unique();
+    auto filter = FilterGPU_Builder(ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(o.par1).withGPUPlacement(placement).build_unique();
     pipe.add(*filter);
-    auto join = MapGPU_Builder(JoinGPU{table.data(), (uint32_t)campaigns.n_ads()}).withName("ysb_join_gpu").withParallelism(o.par1).build_unique();
+    auto join = MapGPU_Builder(JoinGPU{campaigns.n_ads(), campaigns.ads_per_campaign(), campaigns.inverse_multiplier(), ysb::Campaigns::B})
+                    .withName("ysb_join_gpu").withParallelism(o.par1).withGPUPlacement(placement).build_unique();
     pipe.add(*join);
     auto agg = KeyFarmGPU_Builder(CountWindowGPU())
                    .withTBWindows(std::chrono::microseconds(ysb::WINDOW_US), std::chrono::microseconds(ysb::WINDOW_US))
-                   .withName("ysb_kf_gpu").withParallelism(o.par2).withBatch(64).build_unique();
+                   .withName("ysb_kf_gpu").withParallelism(o.par2).withBatch(64).withGPUPlacement(placement).build_unique();
     pipe.add(*agg);
     Sink sink = Sink_Builder(ysb::ResultSink(&metrics)).withName("ysb_sink").withParallelism(o.par2).build();
     pipe.chain_sink(sink);

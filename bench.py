@@ -100,12 +100,12 @@ def rank_cpus(local_rank, world):
             for run in runs:
                 per = len(run) // len(peers)
                 mine.extend(run[k * per:(k + 1) * per])
-            if len(mine) >= 4:
+            if len(mine) >= 8:
                 return mine
         except OSError:
             pass
     per = len(allowed) // world
-    return allowed[local_rank * per:(local_rank + 1) * per] if per >= 4 else allowed
+    return allowed[local_rank * per:(local_rank + 1) * per] if per >= 8 else allowed
 
 
 def timed_steps(pipe, per_source, steps, barrier):
