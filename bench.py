@@ -69,8 +69,11 @@ def parse_cpulist(text):
 def gpu_numa_node(index):
     """NUMA node of GPU `index` from sysfs (None if unknown)."""
     try:
-        pr = torch.cuda.get_device_properties(index)
-        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        import windflow_amd
+
+        bdf = windflow_amd.load_ext().device_pci_bus_id(index).lower()
+        if not bdf:
+            return None
         with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
             node = int(f.read().strip())
         return node if node >= 0 else None

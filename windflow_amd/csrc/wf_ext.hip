@@ -473,6 +473,11 @@ static std::vector<std::vector<double>> exchange_local_run(int gpu_id, int world
 PYBIND11_MODULE(_C, m) {
     m.doc() = "windflow_amd native extension (gfx950)";
     m.def("device_count", &gpu::device_count);
+    m.def("device_pci_bus_id", [](int device) {
+        char buf[64] = {0};
+        if (hipDeviceGetPCIBusId(buf, (int)sizeof(buf), device) != hipSuccess) return std::string();
+        return std::string(buf);
+    }, py::arg("device"), "PCI address (domain:bus:device.function) of a GPU, without creating a context on it");
     m.def("tuple_size", []() { return sizeof(tuple_t); });
     m.def("map_scale_inplace", &map_scale_inplace, py::arg("tuples"), py::arg("n"), py::arg("factor"));
     m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
