@@ -86,3 +86,32 @@ def test_ops_key_ffat_and_model_pipeline():
         m.step(10_000)
         st = m.stats()
     assert st["sink_tuples"] == sum(1 for s in range(2) for q in range(10_000) if (q & 1023) * 2 + 1 < 1024)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from windflow_amd import parallel
+
+    env = parallel.init_distributed("gloo")
+    q.put((rank, env.world, parallel.all_reduce_max(10.0 + rank, env)))
+    parallel.shutdown()
+
+
+def test_parallel_control_plane_two_processes_gloo():
+    """The control plane of a multi-rank job (rendezvous + max-reduction of the timings) with 2 CPU processes."""
+    import socket
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, 2, 11.0), (1, 2, 11.0)]
