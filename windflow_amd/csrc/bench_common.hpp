@@ -3,6 +3,7 @@
 // gpu_map_stateful.cpp:80-85), a fast synthetic generator, and the step gate /
 // barrier that lets a driver time "K steps" on a persistent streaming graph.
 #pragma once
+#include <cstdlib>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -127,14 +128,25 @@ public:
         const uint64_t src = ctx.getReplicaIndex() + src_offset_;
         uint64_t seq = seq_, kc = kc_, round = round_;
         const uint64_t nk = n_keys_, ns = n_sources_, tstep = ts_step_;
+        const bool nt = nt_stores_;
         // keys of different sources are disjoint (key % n_sources == src): per-key order is
         // then well defined without cross-source ordering
         for (int64_t i = 0; i < take; i++, seq++) {
-            buf[i].key = kc * ns + src;
-            buf[i].id = round;
-            buf[i].ts = seq * tstep;
-            buf[i].value = (double)(seq & 1023);
-            buf[i].aux = 1.0;
+            if (nt) {
+                // non-temporal stores: the slab is only read back by the DMA engine; not pulling its lines into the
+                // cache first saves the read-for-ownership traffic when many ranks share the host memory system
+                __builtin_nontemporal_store(kc * ns + src, &buf[i].key);
+                __builtin_nontemporal_store(round, &buf[i].id);
+                __builtin_nontemporal_store(seq * tstep, &buf[i].ts);
+                __builtin_nontemporal_store((double)(seq & 1023), &buf[i].value);
+                __builtin_nontemporal_store(1.0, &buf[i].aux);
+            } else {
+                buf[i].key = kc * ns + src;
+                buf[i].id = round;
+                buf[i].ts = seq * tstep;
+                buf[i].value = (double)(seq & 1023);
+                buf[i].aux = 1.0;
+            }
             if (++kc == nk) {
                 kc = 0;
                 round++;
@@ -160,6 +172,8 @@ private:
     uint64_t seq_ = 0, kc_ = 0, round_ = 0;
     uint64_t punct_ = 0;
     uint64_t opened_ns_ = 0;
+    // on by default (single GPU: same throughput, lower p99 latency; several ranks: less host memory traffic); WF_BENCH_NT_STORES=0 disables
+    bool nt_stores_ = std::getenv("WF_BENCH_NT_STORES") == nullptr || std::atoi(std::getenv("WF_BENCH_NT_STORES")) != 0;
 };
 
 }  // namespace wfbench
