@@ -35,7 +35,9 @@ def parse_args():
     p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "win_agg"),
                    help="win_agg: keyed sliding-window aggregation (flagship); map_filter: stateless Map_GPU+Filter_GPU")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
-    p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", str(256 * 1024))))
+    p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", "0")),
+                   help="tuples per batch; default 128 Ki with 4 batches in flight per lane (dp: the throughput plateau at half "
+                        "the latency of 256 Ki x 6), 256 Ki x 6 for keyby (one fat aggregation lane wants large kernels)")
     p.add_argument("--keys", type=int, default=int(os.environ.get("WF_BENCH_KEYS", str(1 << 20))),
                    help="distinct keys per GPU (all resident in HBM)")
     p.add_argument("--win", type=int, default=16, help="window length, in tuples of one key")
@@ -43,7 +45,7 @@ def parse_args():
     p.add_argument("--count-based", action="store_true", help="count-based instead of time-based windows")
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
                    help="tuples fed per GPU per step")
-    p.add_argument("--inflight", type=int, default=6)
+    p.add_argument("--inflight", type=int, default=0)
     p.add_argument("--agg-replicas", type=int, default=int(os.environ.get("WF_BENCH_AGG_REPLICAS", "0")),
                    help="keyby mode: Key_FFAT_GPU replicas behind the exchange (0: default)")
     p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
@@ -134,8 +136,8 @@ def run_exchange_probe(args, world, limit_s=90):
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.exchange_probe_steps), "--warmup", "1",
            "--parallelism", "keyby", "--exchange-probe-steps", "0", "--pipeline", "win_agg", "--sources", str(args.sources),
-           "--batch", str(args.batch), "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
-           "--tuples-per-step", str(args.tuples_per_step), "--inflight", str(args.inflight), "--no-cpu-partition"]
+           "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
+           "--tuples-per-step", str(args.tuples_per_step), "--no-cpu-partition"]
     if args.count_based:
         cmd.append("--count-based")
     print("[bench] timed run done; probing the keyby exchange in a child process (limit %d s)" % limit_s, file=sys.stderr, flush=True)
@@ -168,6 +170,10 @@ def run_exchange_probe(args, world, limit_s=90):
 
 def main():
     args = parse_args()
+    if args.batch <= 0:
+        args.batch = 256 * 1024 if args.parallelism == "keyby" else 128 * 1024
+    if args.inflight <= 0:
+        args.inflight = 6 if args.parallelism == "keyby" else 4
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
