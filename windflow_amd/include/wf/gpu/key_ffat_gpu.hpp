@@ -427,6 +427,36 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             }
         }
         wave_sync_lds();
+        // bulk path: panes written to the working tree whose windows have not been evaluated yet.  Rebuilding the
+        // tree and evaluating windows costs the same for 1 or 64 new panes, so chunks that complete few panes
+        // (long panes) are accumulated until 64 panes are pending.
+        uint32_t pend = 0;
+        decltype(cf_key(st.partial)) run_key{};
+        auto fire_pending = [&]() {
+            if (pend == 0) return;
+            fat_rebuild_wave(ltree, CW, comb);
+            // windows k in [next_lwid, k_end), window k = panes [k*slide, k*slide + win)
+            const uint64_t Pn = st.panes;
+            const uint64_t k_end = Pn >= g.win_panes ? (Pn - g.win_panes) / g.slide_panes + 1 : 0;
+            const uint32_t nf = k_end > st.next_lwid ? (uint32_t)(k_end - st.next_lwid) : 0;  // <= pend <= 64
+            // results are parked in LDS and leave with one atomic when the 64 slots are full (or at the end of the
+            // run): a returning global atomic per chunk would dominate chunks that fire few windows
+            if (emit.n + nf > (uint32_t)WAVE) {
+                emit.flush_wave();
+                wave_sync_lds();
+            }
+            if ((uint32_t)lane < nf) {
+                const uint64_t k = st.next_lwid + (uint64_t)lane;
+                R res;
+                fat_query_circular(ltree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
+                res.setControlFields(run_key, k, cf_ts(res));
+                emit.buf[emit.n + (uint32_t)lane] = res;
+            }
+            emit.n += nf;
+            if (k_end > st.next_lwid) st.next_lwid = k_end;
+            pend = 0;
+            wave_sync_lds();
+        };
         // software pipeline: chunk c+1 is loaded into registers before chunk c is reduced
         uint32_t j = head + lane;
         bool ok = (j < n) && (sslot[j] == slot);
@@ -489,6 +519,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 if (!g.is_tb) {
                     const uint32_t total = pc0 + cnt;
                     m = (uint32_t)(total / g.pane_len);
+                    if (pend + m > (uint32_t)WAVE) fire_pending();
                     if (tail) {
                         if (seg == 0 && pc0 > 0) fat_combine(comb, st.partial, val, open_val);
                         if ((uint32_t)seg < m) ltree[CW + (uint32_t)((P + (uint64_t)seg) & (CW - 1))] = open_val;
@@ -500,6 +531,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 } else {
                     const uint64_t Lq = st.last_quantum;
                     m = (uint32_t)(q_last - Lq);
+                    if (pend + m > (uint32_t)WAVE) fire_pending();
                     const uint32_t amask = g.acc_cap - 1;
                     const bool open_used = lused[(uint32_t)(Lq & amask)] != 0;
                     // every completed quantum starts as an empty pane ...
@@ -531,33 +563,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     if (q_last + 1 > st.max_quantum) st.max_quantum = q_last + 1;
                 }
                 st.seen = 1;
+                st.panes = P + m;
+                pend += m;
+                run_key = key;
                 wave_sync_lds();
-                if (m > 0) {
-                    fat_rebuild_wave(ltree, CW, comb);
-                    // windows fired by the chunk: k in [next_lwid, k_end), window k = panes [k*slide, k*slide + win)
-                    const uint64_t Pn = P + m;
-                    const uint64_t k_end = Pn >= g.win_panes ? (Pn - g.win_panes) / g.slide_panes + 1 : 0;
-                    const uint32_t nf = k_end > st.next_lwid ? (uint32_t)(k_end - st.next_lwid) : 0;  // <= m <= 64
-                    // results are parked in LDS and leave with one atomic when the 64 slots are full (or at the end
-                    // of the run): a returning global atomic per chunk would dominate chunks that fire few windows
-                    if (emit.n + nf > (uint32_t)WAVE) {
-                        emit.flush_wave();
-                        wave_sync_lds();
-                    }
-                    if ((uint32_t)lane < nf) {
-                        const uint64_t k = st.next_lwid + (uint64_t)lane;
-                        R res;
-                        fat_query_circular(ltree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
-                        res.setControlFields(key, k, cf_ts(res));
-                        emit.buf[emit.n + (uint32_t)lane] = res;
-                    }
-                    emit.n += nf;
-                    if (k_end > st.next_lwid) st.next_lwid = k_end;
-                    st.panes = Pn;
-                    wave_sync_lds();
-                }
             } else {
-                // sequential rules, one step per segment, by lane 0
+                // sequential rules, one step per segment, by lane 0 (on a consistent tree: fire what is pending first)
+                fire_pending();
                 if (tail) {
                     const int first = 63 - __builtin_clzll(upto_me);  // lane of my segment's boundary
                     segs[seg].agg = val;
@@ -592,6 +604,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             reg = nreg;
             ok = nok;
         }
+        fire_pending();
         emit.flush_wave();  // whatever the last chunks parked
         wave_sync_lds();
         if (bulk) {
