@@ -266,3 +266,58 @@ def test_key_ffat_skips_long_empty_stretches_when_asked(ext, n_keys, batch):
         assert k in got and got[k][0] == pytest.approx(s, abs=1e-9), k
     assert len(got) + ctr["skipped_windows"] == total_windows
     assert len(got) < total_windows // 10
+
+
+# ---- randomised cross-check of every engine path against the oracles ----------------------------------------------
+
+def _fuzz_cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n_cases):
+        tb = bool(rng.integers(0, 2))
+        slide = int(rng.integers(1, 40))
+        win = slide + int(rng.integers(1, 200)) if rng.integers(0, 3) else slide * int(rng.integers(2, 9))
+        n_keys = int(rng.choice([1, 2, 3, 9, 40, 300, 2500]))
+        n = int(rng.integers(2000, 40000))
+        batch = int(rng.choice([257, 1000, 2048, 4096, 16384]))
+        gap_every = int(rng.choice([10**9, 50, 400, 3000]))
+        gap_len = int(rng.choice([3, 60, 2500]))
+        disorder = int(rng.choice([0, 0, 5, 40])) if tb else 0
+        delay = 0 if disorder == 0 else disorder + int(rng.integers(1, 30))
+        mode = int(rng.choice([0, 1, 2])) if not tb else 0
+        cases.append((i, tb, n, n_keys, win, slide, batch, gap_every, gap_len, disorder, delay, mode))
+    return cases
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(int(_os.environ.get("WF_FUZZ_CASES", "40")), seed=int(_os.environ.get("WF_FUZZ_SEED", "20260101"))),
+                         ids=lambda c: "case%d" % c[0])
+def test_key_ffat_fuzz(ext, case):
+    i, tb, n, n_keys, win, slide, batch, gap_every, gap_len, disorder, delay, mode = case
+    if tb:
+        t, vals = bursty_stream(n, n_keys, seed=1000 + i, gap_every=gap_every, gap_len=gap_len, disorder=disorder)
+    else:
+        t, vals = make_stream(n, n_keys, seed=1000 + i)
+    res, ctr = ext.key_ffat_run(t, win, slide, delay, tb, max(16, n_keys), batch, 1 << 19, mode)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    got = unpack(res)
+    assert len(got) == len(res), "duplicate (key, window) results"
+    if tb:
+        exp = oracle_tb(t, vals, win, slide)
+        assert len(got) == len(exp)
+        for k, s in exp.items():
+            assert got[k][0] == pytest.approx(s, abs=1e-9), (case, k)
+    else:
+        n_exp = 0
+        for key in np.unique(t[:, 0]):
+            v = vals[t[:, 0] == key]
+            lw = 0
+            while lw * slide < len(v):
+                w = v[lw * slide:lw * slide + win]
+                e = w.sum() if mode == 0 else (w[-1] if mode == 1 else w[0])
+                assert got[(int(key), lw)][0] == pytest.approx(e, abs=1e-9), (case, key, lw)
+                lw += 1
+                n_exp += 1
+        assert len(got) == n_exp
