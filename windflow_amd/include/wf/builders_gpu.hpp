@@ -46,6 +46,10 @@ public:
         return this->self();
     }
     Derived& withScratchpadSize(size_t bytes) { return withScratchpad(bytes); }
+    // source compatibility with the fork's MapGPU_Builder (wf/builders_gpu.hpp:1512-1520): whether an operator takes
+    // or leaves its batches on the device is negotiated by the MultiPipe, so these are accepted and ignored
+    Derived& withGPUInput() { return this->self(); }
+    Derived& withGPUOutput() { return this->self(); }
     // batches in flight per replica (depth of the shipping pipeline)
     Derived& withInFlightBatches(size_t n) {
         cfg_.pool_slabs = n < 2 ? 2 : n;
