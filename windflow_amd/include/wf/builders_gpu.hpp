@@ -99,6 +99,9 @@ public:
         routing_ = std::move(r);
         return *this;
     }
+    // fork spelling (wf/builders_gpu.hpp:1507, :1522): keyedness comes from the functor signature here
+    MapGPU_Builder& withKeyBy(bool) { return *this; }
+    MapGPU_Builder& withRoutingFunction(routing_func_t r) { return enable_KeyBy(std::move(r)); }
     MapGPU_Builder& withKeyDisjointLanes(bool b = true) {
         kcfg_.lanes_are_key_disjoint = b;
         return *this;
@@ -143,6 +146,8 @@ public:
         routing_ = std::move(r);
         return *this;
     }
+    FilterGPU_Builder& withKeyBy(bool) { return *this; }
+    FilterGPU_Builder& withRoutingFunction(routing_func_t r) { return enable_KeyBy(std::move(r)); }
     FilterGPU_Builder& withKeyDisjointLanes(bool b = true) {
         kcfg_.lanes_are_key_disjoint = b;
         return *this;

@@ -86,6 +86,7 @@ public:
 
     bool isRunnable() const { return has_source_ && (has_sink_ || is_merged_ || is_split_); }
     bool hasSink() const { return has_sink_; }
+    bool hasSource() const { return has_source_; }
     size_t getNumEndpoints() const { return tails_.size(); }
 
 private:
