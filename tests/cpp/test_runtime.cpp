@@ -269,6 +269,32 @@ static void test_stats_and_dot() {
     CHECK(in_map == 3000);
 }
 
+// ---- late tuples are dropped and accounted (DEFAULT mode, time-based windows) -----------------------------------
+static void test_dropped_tuples() {
+    PipeGraph graph("late", Mode::DEFAULT);
+    long v = 0;
+    // timestamps advance by 10; every 100th tuple is 5000 time units late (several windows in the past)
+    Source src = Source_Builder([=](rec_t& t) mutable {
+                     const uint64_t ts = (v % 100 == 99 && v > 1000) ? (uint64_t)(v * 10 - 5000) : (uint64_t)(v * 10);
+                     t.setControlFields(0, (uint64_t)v, ts);
+                     t.value = 1;
+                     return ++v < 5000;
+                 }).withParallelism(1).build();
+    MultiPipe& mp = graph.add_source(src);
+    Key_Farm kf = KeyFarm_Builder([](uint64_t, const rec_t& t, rec_t& out) { out.value += t.value; })
+                      .withTBWindows(std::chrono::microseconds(200), std::chrono::microseconds(100)).withParallelism(1).build();
+    mp.add(kf);
+    atomic<long> counted{0};
+    Sink s = Sink_Builder([&](optional<rec_t>& r) {
+                 if (r) counted += r->value;
+             }).withParallelism(1).build();
+    mp.add_sink(s);
+    graph.run();
+    const long late = (5000 - 1000) / 100;  // tuples 1099, 1199, ... 4999
+    CHECK((long)kf.getNumDroppedTuples() == late);
+    CHECK(counted == 2 * (5000 - late) - 10);  // every on-time tuple is in two windows, except the first 10 (window [-100, 100) does not exist)
+}
+
 // ---- illegal topologies must be refused -----------------------------------------------
 static int illegal(int which) {
     PipeGraph graph("illegal", Mode::DEFAULT);
@@ -330,6 +356,7 @@ int main(int argc, char** argv) {
     test_string_keys();
     test_flatfat();
     test_stats_and_dot();
+    test_dropped_tuples();
     cout << (failures == 0 ? "ALL OK" : "FAILED") << endl;
     return failures == 0 ? 0 : 1;
 }

@@ -101,6 +101,14 @@ public:
         return hub_->recs;
     }
 
+    // tuples discarded by the replicas (late tuples of window operators, reference: getNumDroppedTuples,
+    // wf/win_farm.hpp:592-617; tuples rejected by a Filter); valid once the PipeGraph has ended
+    size_t getNumDroppedTuples() const {
+        size_t n = 0;
+        for (const Stats_Record& r : get_StatsRecords()) n += r.inputs_ignored;
+        return n;
+    }
+
     void mark_used() { used_ = true; }
     std::shared_ptr<StatsHub> stats_hub() const { return hub_; }
 

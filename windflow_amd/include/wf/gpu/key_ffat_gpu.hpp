@@ -941,6 +941,7 @@ protected:
         while (engine_->flush_range(cursor, this->stream(), this->num_kernels_, out)) this->emit_device(out);
         const gpu::FFATCounters c = engine_->read_counters(this->stream());
         if (counters_) (*counters_)[this->context.getReplicaIndex()] = c;
+        dropped_ = c.dropped;
         // losing results silently is not an option: fail loudly and say which knob to turn
         if (c.overflow > 0)
             fatal_error("Key_FFAT_GPU: " + std::to_string(c.overflow) + " window results did not fit the output batches; raise the output capacity "
@@ -949,7 +950,13 @@ protected:
             fatal_error("Key_FFAT_GPU: the device key table is full; raise KeyFFATGPU_Builder::withMaxKeys");
     }
 
+    void finalize_stats(Stats_Record& s) override {
+        GPU_Replica<tuple_t>::finalize_stats(s);
+        s.inputs_ignored = dropped_;  // late tuples, counted on the device
+    }
+
 private:
+    uint64_t dropped_ = 0;
     L lift_;
     C comb_;
     KeyFFATGPUConfig wcfg_;
