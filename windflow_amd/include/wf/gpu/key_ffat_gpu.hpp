@@ -489,12 +489,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             const unsigned long long bmask = __ballot(boundary);
             const unsigned long long upto_me = bmask & (lanemask_lt() | (1ull << lane));
             const int seg = __popcll(upto_me) - 1;
-            // 3. order-preserving segmented inclusive scan
-#pragma unroll
+            // 3. order-preserving segmented inclusive scan; segments are contiguous, so once no lane finds a member
+            //    of its segment d lanes below, no larger distance can either (short panes stop after 2-3 steps)
             for (int d = 1; d < WAVE; d <<= 1) {
-                const R other = wave_shfl_up(val, d);
                 const int oseg = __shfl_up(seg, d, WAVE);
-                if (ok && lane >= d && oseg == seg) {
+                const bool take = ok && lane >= d && oseg == seg;
+                if (__ballot(take) == 0) break;
+                const R other = wave_shfl_up(val, d);
+                if (take) {
                     R tmp;
                     fat_combine(comb, other, val, tmp);
                     val = tmp;
