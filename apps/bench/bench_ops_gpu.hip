@@ -59,17 +59,25 @@ struct WindowState {
     double values[CAP];
     double sum;
     uint32_t first, last, count, pad;
+    // the header is read once and written once per tuple (independent loads, one round trip), the
+    // ring buffer touched at most twice: the function is latency-bound, one tuple of a key after the other
     __host__ __device__ double push(double v) {
-        if (count == CAP) {
-            sum -= values[first];
-            first = first + 1 == CAP ? 0 : first + 1;
+        uint32_t f = first, l = last, c = count;
+        double s = sum;
+        if (c == CAP) {
+            s -= values[f];
+            f = f + 1 == CAP ? 0 : f + 1;
         } else {
-            count++;
+            c++;
         }
-        values[last] = v;
-        last = last + 1 == CAP ? 0 : last + 1;
-        sum += v;
-        return sum / count;
+        values[l] = v;
+        l = l + 1 == CAP ? 0 : l + 1;
+        s += v;
+        first = f;
+        last = l;
+        count = c;
+        sum = s;
+        return s / c;
     }
 };
 struct RunningAverageMap {

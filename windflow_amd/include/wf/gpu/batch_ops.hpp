@@ -131,19 +131,20 @@ private:
         while (!fifo_.empty()) {
             InFlight& f = fifo_.front();
             if (f.host == nullptr) {
-                // step 1: the count must be known on the host before sizing the copy
+                // step 1: wait on the HOST for the producer (the count must be known before sizing the copy, and a
+                // device-side wait would park a barrier packet in this stream's hardware queue, which it shares
+                // with other lanes' compute streams: their kernels would queue up behind this lane's)
+                if (block)
+                    f.dev->ready.host_sync();
+                else if (!f.dev->ready.done())
+                    return;
                 if (!f.dev->count_on_host) {
-                    if (block)
-                        f.dev->ready.host_sync();
-                    else if (!f.dev->ready.done())
-                        return;
                     f.dev->host_hdr.count = *f.dev->count_mirror;
                     f.dev->count_on_host = true;
                 }
                 gpu::TraceRange tr("wf:drain_batch");
                 gpu::Batch* h = pool_->acquire_host();
                 h->host_hdr = f.dev->host_hdr;
-                f.dev->ready.wait_on(*stream_);
                 const size_t bytes = (size_t)h->host_hdr.count * sizeof(T);
                 if (bytes > 0) WF_HIP_CHECK(hipMemcpyAsync(h->template data<T>(), f.dev->template data<T>(), bytes, hipMemcpyDeviceToHost, *stream_));
                 h->ready.record(*stream_);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -155,9 +156,10 @@ public:
         WF_HIP_CHECK(hipEventRecord(e_, s));
         recorded_ = true;
     }
-    // make stream s wait for the event (no-op if never recorded)
+    // make stream s wait for the event (no-op if never recorded or already complete: a wait parks a barrier
+    // packet in the stream's hardware queue, which other streams share)
     void wait_on(hipStream_t s) const {
-        if (recorded_) WF_HIP_CHECK(hipStreamWaitEvent(s, e_, 0));
+        if (!done()) WF_HIP_CHECK(hipStreamWaitEvent(s, e_, 0));
     }
     void host_sync() const {
         if (recorded_) WF_HIP_CHECK(hipEventSynchronize(e_));
@@ -274,8 +276,9 @@ private:
             return nb;
         }
         cv_.wait(l, [this] { return !free_.empty(); });
-        Batch* b = free_.back();
-        free_.pop_back();
+        // oldest release first: its last use is the most likely to be complete already
+        Batch* b = free_.front();
+        free_.pop_front();
         return b;
     }
     static void reset(Batch* b) {
@@ -305,7 +308,7 @@ private:
     size_t elem_size_, capacity_, max_slabs_;
     std::mutex m_;
     std::condition_variable cv_;
-    std::vector<Batch*> free_;
+    std::deque<Batch*> free_;
     std::vector<Batch*> all_;
 };
 

@@ -74,6 +74,31 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// A tuple held in registers as plain words between a global load and a later store.  A struct copied through a
+// private temporary under divergent control flow is not always promoted to registers by the compiler and then
+// lives in scratch memory (a memory round trip per tuple); an unrolled word array always is.
+template <typename T>
+struct TupleWords {
+    static constexpr int N = sizeof(T) / 4;
+    static constexpr int REM = sizeof(T) % 4;
+    typedef uint32_t __attribute__((may_alias)) word_t;
+    typedef uint8_t __attribute__((may_alias)) byte_t;
+    uint32_t w[N > 0 ? N : 1];
+    uint8_t tail[REM > 0 ? REM : 1];
+    __device__ __forceinline__ void load(const T* p) {
+#pragma unroll
+        for (int k = 0; k < N; k++) w[k] = reinterpret_cast<const word_t*>(p)[k];
+#pragma unroll
+        for (int k = 0; k < REM; k++) tail[k] = reinterpret_cast<const byte_t*>(p)[4 * N + k];
+    }
+    __device__ __forceinline__ void store(T* p) const {
+#pragma unroll
+        for (int k = 0; k < N; k++) reinterpret_cast<word_t*>(p)[k] = w[k];
+#pragma unroll
+        for (int k = 0; k < REM; k++) reinterpret_cast<byte_t*>(p)[4 * N + k] = tail[k];
+    }
+};
+
 // ---- K9: fused filter + stable stream compaction ----------------------------
 // workspace layout: ws[0] = ticket counter, ws[1..] = tile descriptors.
 // descriptor = (status << 32) | value; status 0 = empty, 1 = tile aggregate,
@@ -98,9 +123,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     const uint32_t tile = s_tile;
     if (n_tiles == 0) {
         if (tile == 0 && threadIdx.x == 0) {
-            BatchHeader h = *in_hdr;
-            h.count = 0;
-            *out_hdr = h;
+            *out_hdr = *in_hdr;
+            out_hdr->count = 0;
             if (count_mirror) *count_mirror = 0;
         }
         return;
@@ -112,7 +136,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     const uint32_t base = tile * FILTER_TILE;
 
     // 1. predicate + in-wave rank (striped: item k of thread t is element base + k*256 + t)
-    T vals[FILTER_ITEMS];
+    TupleWords<T> vals[FILTER_ITEMS];
     bool keep[FILTER_ITEMS];
     uint32_t rank[FILTER_ITEMS];
 #pragma unroll
@@ -120,8 +144,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t idx = base + k * BLOCK_THREADS + threadIdx.x;
         keep[k] = false;
         if (idx < n) {
-            vals[k] = in[idx];
-            keep[k] = pred(vals[k], idx);
+            vals[k].load(in + idx);
+            keep[k] = pred(in[idx], idx);
         }
         const unsigned long long b = __ballot(keep[k]);
         rank[k] = (uint32_t)__popcll(b & lanemask_lt());
@@ -174,9 +198,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         if (lane == 0) {
             s_base = exclusive;
             if (tile == n_tiles - 1) {
-                BatchHeader h = *in_hdr;
-                h.count = exclusive + tile_total;
-                *out_hdr = h;
+                *out_hdr = *in_hdr;
+                out_hdr->count = exclusive + tile_total;
                 if (count_mirror) *count_mirror = exclusive + tile_total;
             }
         }
@@ -186,7 +209,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     const uint32_t gbase = s_base;
 #pragma unroll
     for (int k = 0; k < FILTER_ITEMS; k++) {
-        if (keep[k]) out[gbase + my_off[k] + rank[k]] = vals[k];
+        if (keep[k]) vals[k].store(out + gbase + my_off[k] + rank[k]);
     }
 }
 

@@ -67,23 +67,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-// lane 0 of a wave applies the user function to the `cnt` staged tuples of a chunk, in order
+// lane 0 of a wave applies the user function to the `cnt` staged tuples of a chunk, in order and in place
+// (the function reads and writes the staged tuple / result directly: no private copies)
 template <int MODE, typename T, typename R, typename F>
 __device__ __forceinline__ void keyed_apply_chunk(T* stage, R* rstage, uint8_t* fstage, uint32_t cnt, char* st, size_t state_size, F& f) {
     for (uint32_t u = 0; u < cnt; u++) {
         if constexpr (MODE == 0) {
-            T t = stage[u];
-            f(t, st, state_size);
-            stage[u] = t;
+            f(stage[u], st, state_size);
         } else if constexpr (MODE == 1) {
-            const T t = stage[u];
-            R res{};
-            f(t, res, st, state_size);
-            rstage[u] = res;
+            rstage[u] = R{};
+            f(static_cast<const T&>(stage[u]), rstage[u], st, state_size);
         } else {
-            const T t = stage[u];
             bool keep = false;
-            f(t, keep, st, state_size);
+            f(static_cast<const T&>(stage[u]), keep, st, state_size);
             fstage[u] = keep ? 1 : 0;
         }
     }
@@ -123,11 +119,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         uint32_t j = head + lane;
         bool ok = (j < n) && (sslot[j] == slot);
         uint32_t p = ok ? sidx[j] : 0;
-        T reg{};
-        if (ok) reg = data[p];
+        TupleWords<T> reg;
+        if (ok) reg.load(data + p);
         while (true) {
             const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));  // valid lanes are a prefix: the arrays are sorted
-            if (ok) stage[lane] = reg;
+            if (ok) reg.store(stage + lane);
             const uint32_t my_p = p;
             const bool my_ok = ok;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -139,7 +135,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 j += WAVE;
                 ok = (j < n) && (sslot[j] == slot);
                 p = ok ? sidx[j] : 0;
-                if (ok) reg = data[p];
+                if (ok) reg.load(data + p);
             }
             if (lane == 0) {
                 // two copies of the loop so that the compiler knows the address space of the state in each
