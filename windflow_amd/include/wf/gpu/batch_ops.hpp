@@ -105,7 +105,12 @@ public:
         gpu::Batch* d = static_cast<gpu::Batch*>(msg);
         if (!stream_) {
             WF_HIP_CHECK(hipSetDevice(d->device));
-            stream_.reset(new gpu::Stream());
+            if (gpu::d2h_shared_stream()) {
+                stream_ = gpu::shared_copy_stream(d->device);
+            } else {
+                own_stream_.reset(new gpu::Stream());
+                stream_ = own_stream_->get();
+            }
             pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, d->device, sizeof(T), d->capacity, depth_ + 2));
         }
         fifo_.push_back({d, nullptr});
@@ -114,7 +119,7 @@ public:
     }
     void flush() override {
         while (!fifo_.empty()) pump(true);
-        if (stream_) stream_->sync();
+        if (stream_) WF_HIP_CHECK(hipStreamSynchronize(stream_));
     }
     bool wants_idle() const override { return true; }
     void on_idle() override {
@@ -146,9 +151,9 @@ private:
                 gpu::Batch* h = pool_->acquire_host();
                 h->host_hdr = f.dev->host_hdr;
                 const size_t bytes = (size_t)h->host_hdr.count * sizeof(T);
-                if (bytes > 0) WF_HIP_CHECK(hipMemcpyAsync(h->template data<T>(), f.dev->template data<T>(), bytes, hipMemcpyDeviceToHost, *stream_));
-                h->ready.record(*stream_);
-                f.dev->release(*stream_);
+                if (bytes > 0) WF_HIP_CHECK(hipMemcpyAsync(h->template data<T>(), f.dev->template data<T>(), bytes, hipMemcpyDeviceToHost, stream_));
+                h->ready.record(stream_);
+                f.dev->release(stream_);
                 f.host = h;
             }
             // step 2: copy completion
@@ -162,7 +167,8 @@ private:
         }
     }
     size_t depth_;
-    std::unique_ptr<gpu::Stream> stream_;
+    hipStream_t stream_ = nullptr;  // own_stream_, or the device's shared copy stream (WF_D2H_STREAMS=shared)
+    std::unique_ptr<gpu::Stream> own_stream_;
     std::unique_ptr<gpu::BatchPool> pool_;
     std::deque<InFlight> fifo_;
 };
@@ -375,7 +381,14 @@ public:
                 staging_->release_host();
             staging_ = nullptr;
         }
+        while (!uploading_.empty()) pump_uploads(true);
         gpu_flush();
+    }
+
+    // uploads complete while the input queue is empty: hand them to the kernels without waiting for the next batch
+    bool wants_idle() const override { return in_kind_ != EDGE_DEVICE_BATCH; }
+    void on_idle() override {
+        if (!uploading_.empty()) pump_uploads(false);
     }
 
     void svc_end() override {
@@ -434,23 +447,52 @@ private:
         mine->ready.record(stream());
         return mine;
     }
-    // host batch -> device batch (async), then run the operator on it
+    // host batch -> device batch (async), then the operator's kernels: on the replica's compute stream, or with
+    // WF_UPLOAD_STREAMS=n on a shared upload stream, the kernels following once the copy is known to be complete
     void ship(gpu::Batch* h) {
         gpu::TraceRange tr("wf:ship_batch");
-        if (!dev_in_pool_)
+        if (!dev_in_pool_) {
             dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), h->capacity, cfg_.pool_slabs));
-        gpu::Batch* d = dev_in_pool_->acquire(stream());
+            upload_stream_ = gpu::upload_streams() == 0
+                                 ? stream()
+                                 : gpu::shared_copy_stream(cfg_.gpu_id, 1 + (int)(this->context.getReplicaIndex() % gpu::upload_streams()));
+        }
+        gpu::Batch* d = dev_in_pool_->acquire(upload_stream_);
         *h->header() = h->host_hdr;  // the header travels in the slab
         const size_t bytes = h->bytes_used();
-        WF_HIP_CHECK(hipMemcpyAsync(d->slab, h->slab, bytes, hipMemcpyHostToDevice, stream()));
+        WF_HIP_CHECK(hipMemcpyAsync(d->slab, h->slab, bytes, hipMemcpyHostToDevice, upload_stream_));
         bytes_hd_ += bytes;
         d->host_hdr = h->host_hdr;
         d->count_on_host = true;
-        h->release(stream());
-        process_device(d);
-        WF_HIP_CHECK(hipGetLastError());  // a refused launch (bad grid, too much LDS) must not pass silently
+        h->release(upload_stream_);
+        if (upload_stream_ == stream()) {  // uploads in the compute stream: stream order is all the kernels need
+            process_device(d);
+            WF_HIP_CHECK(hipGetLastError());
+            return;
+        }
+        d->ready.record(upload_stream_);
+        uploading_.push_back(d);
+        pump_uploads(false);
+        // double buffering: at most one upload in flight behind the batch being handed to the kernels
+        while (uploading_.size() > 1) pump_uploads(true);
+    }
+    void pump_uploads(bool block) {
+        while (!uploading_.empty()) {
+            gpu::Batch* d = uploading_.front();
+            if (block)
+                d->ready.host_sync();
+            else if (!d->ready.done())
+                return;
+            uploading_.pop_front();
+            gpu::TraceRange tr("wf:enqueue_kernels");
+            process_device(d);
+            WF_HIP_CHECK(hipGetLastError());  // a refused launch (bad grid, too much LDS) must not pass silently
+            block = false;
+        }
     }
 
+    hipStream_t upload_stream_ = nullptr;
+    std::deque<gpu::Batch*> uploading_;
     std::unique_ptr<gpu::Stream> stream_;
     std::unique_ptr<gpu::BatchPool> staging_pool_;
     std::unique_ptr<gpu::BatchPool> dev_in_pool_;

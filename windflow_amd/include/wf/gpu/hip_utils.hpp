@@ -143,6 +143,60 @@ private:
     hipStream_t s_ = nullptr;
 };
 
+// Streams and hardware queues.  The streams of a process are spread over a few hardware queues (4 by default,
+// GPU_MAX_HW_QUEUES); streams that share a queue run their kernels one after the other, and a stream that waits
+// ON THE DEVICE for an event of another stream parks a barrier packet that holds up every other stream of its
+// queue until the event fires.  The runtime therefore waits on the HOST wherever a lane depends on another
+// stream (a recycled slab's last use, the producer of a batch to download): the calling thread has nothing
+// else to enqueue anyway, and the queues only ever hold work that can run.  Measured on MI355X
+// (apps/bench/ab_sync.sh, profiles/r1_sync_policy): stateful Map_GPU at 1024 keys 0.59-0.81 -> 0.90-0.97 G
+// tuples/s, flagship at 64 keys 0.57 -> 0.70 G, at 1 Mi keys 1.14-1.21 -> 1.20-1.26 G.
+//
+// Optional copy streams shared by all lanes of a device (slot 0: device->host adapters with WF_D2H_STREAMS=shared,
+// slots 1..: uploads with WF_UPLOAD_STREAMS=n): one copy at a time in FIFO order instead of one per lane.  They
+// measured SLOWER than per-lane streams on this hardware and are off by default.  Never destroyed: nodes of any
+// thread may hold them until the process ends.
+inline hipStream_t shared_copy_stream(int device, int slot = 0) {
+    constexpr int SLOTS = 8;
+    static std::mutex m;
+    static std::vector<hipStream_t> streams;
+    std::lock_guard<std::mutex> l(m);
+    const size_t at = (size_t)device * SLOTS + (size_t)(slot % SLOTS);
+    if (at >= streams.size()) streams.resize((size_t)(device + 1) * SLOTS, nullptr);
+    if (!streams[at]) {
+        WF_HIP_CHECK(hipSetDevice(device));
+        WF_HIP_CHECK(hipStreamCreateWithFlags(&streams[at], hipStreamNonBlocking));
+    }
+    return streams[at];
+}
+
+// WF_UPLOAD_STREAMS=n (1..7): uploads go through n shared streams per device and the kernels are enqueued when
+// the copy is known to be complete; default 0: uploads go through each lane's compute stream
+inline size_t upload_streams() {
+    static const size_t n = [] {
+        const char* e = std::getenv("WF_UPLOAD_STREAMS");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v < 0 ? 0 : (v > 7 ? 7 : v));
+    }();
+    return n;
+}
+// WF_POOL_WAIT=device: a recycled slab's last use is waited for on the device (stream-ordered) instead of the host
+inline bool pool_wait_on_host() {
+    static const bool h = [] {
+        const char* e = std::getenv("WF_POOL_WAIT");
+        return !(e && std::string(e) == "device");
+    }();
+    return h;
+}
+// WF_D2H_STREAMS=shared: the device->host adapters of a device share one stream instead of owning one each
+inline bool d2h_shared_stream() {
+    static const bool h = [] {
+        const char* e = std::getenv("WF_D2H_STREAMS");
+        return e && std::string(e) == "shared";
+    }();
+    return h;
+}
+
 class Event {
 public:
     Event() { WF_HIP_CHECK(hipEventCreateWithFlags(&e_, hipEventDisableTiming)); }
@@ -239,11 +293,15 @@ public:
     BatchPool(const BatchPool&) = delete;
     BatchPool& operator=(const BatchPool&) = delete;
 
-    // acquire for use on `stream` (device work) - stream-ordered, host does not block
-    // unless the pool is exhausted
+    // acquire for device work.  The slab's last use (usually a copy enqueued by a downstream adapter) is waited
+    // for on the HOST: a device-side wait would park a barrier packet in the caller's hardware queue and stall
+    // the other lanes' streams that share it, while the calling thread has nothing else to enqueue anyway.
     Batch* acquire(hipStream_t stream) {
         Batch* b = pop();
-        b->ready.wait_on(stream);
+        if (pool_wait_on_host())
+            b->ready.host_sync();
+        else
+            b->ready.wait_on(stream);
         reset(b);
         return b;
     }
