@@ -38,10 +38,11 @@ def test_gpu_window_operators_default_mode(op):
     assert out.count("  OK") == 2 and "FAILED" not in out
 
 
-def run_keyed_cpp(args, timeout=110):
+def run_keyed_cpp(args, timeout=110, env=None):
     exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_gpu_keyed.hip"), os.path.join(BIN, "test_gpu_keyed"), hip=True,
                             extra=["-I" + os.path.join(HERE, "cpp")])
-    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, WF_QUIET="1", **(env or {})))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 
@@ -51,3 +52,17 @@ def test_keyed_gpu_operators_and_device_keyby(n, keys):
     """Keyed Map_GPU / Filter_GPU (per-key scratchpad state) and Key_FFAT_GPU behind the device KeyBy emitter."""
     out = run_keyed_cpp([n, keys, 2])
     assert out.count("  OK") >= 8 and "FAILED" not in out  # scenarios A, B, C, D x 2 runs (+ E on a box with 2+ GPUs)
+
+
+# the copy / synchronisation policies that are not the default (wf/gpu/hip_utils.hpp) must stay correct
+SYNC_POLICIES = [
+    {"WF_POOL_WAIT": "device"},
+    {"WF_D2H_STREAMS": "shared", "WF_UPLOAD_STREAMS": "2"},
+    {"WF_UPLOAD_STREAMS": "1", "WF_POOL_WAIT": "device", "WF_EDGE_WAIT": "host"},
+]
+
+
+@pytest.mark.parametrize("policy", SYNC_POLICIES, ids=lambda p: ",".join("%s=%s" % kv for kv in sorted(p.items())))
+def test_keyed_gpu_operators_alternative_sync_policies(policy):
+    out = run_keyed_cpp([40000, 37, 1], env=policy)
+    assert out.count("  OK") >= 4 and "FAILED" not in out

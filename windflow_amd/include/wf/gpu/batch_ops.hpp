@@ -362,7 +362,7 @@ public:
             case EDGE_DEVICE_BATCH: {
                 gpu::Batch* d = static_cast<gpu::Batch*>(msg);
                 if (d->device != cfg_.gpu_id) d = pull_from_peer(d);
-                d->ready.wait_on(*stream_);
+                d->ready.edge_wait(*stream_);
                 gpu::TraceRange tr("wf:enqueue_kernels");
                 process_device(d);
                 WF_HIP_CHECK(hipGetLastError());  // a refused launch (bad grid, too much LDS) must not pass silently

@@ -188,6 +188,15 @@ inline bool pool_wait_on_host() {
     }();
     return h;
 }
+// WF_EDGE_WAIT=host|device: how a GPU operator waits for the producer of a DEVICE batch that arrives from another
+// operator's stream
+inline bool edge_wait_on_host() {
+    static const bool h = [] {
+        const char* e = std::getenv("WF_EDGE_WAIT");
+        return e && std::string(e) == "host";
+    }();
+    return h;
+}
 // WF_D2H_STREAMS=shared: the device->host adapters of a device share one stream instead of owning one each
 inline bool d2h_shared_stream() {
     static const bool h = [] {
@@ -218,6 +227,8 @@ public:
     void host_sync() const {
         if (recorded_) WF_HIP_CHECK(hipEventSynchronize(e_));
     }
+    // wait for an event recorded by ANOTHER operator's stream before enqueueing on s (policy: WF_EDGE_WAIT)
+    inline void edge_wait(hipStream_t s) const;
     bool done() const {
         if (!recorded_) return true;
         hipError_t r = hipEventQuery(e_);
@@ -230,6 +241,13 @@ private:
     hipEvent_t e_ = nullptr;
     bool recorded_ = false;
 };
+
+inline void Event::edge_wait(hipStream_t s) const {
+    if (edge_wait_on_host())
+        host_sync();
+    else
+        wait_on(s);
+}
 
 // ---- batches ----------------------------------------------------------------
 // 64-byte header in front of the payload; lives in the same slab as the tuples

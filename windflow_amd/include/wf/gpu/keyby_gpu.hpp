@@ -155,7 +155,7 @@ public:
             d->count_on_host = true;
             b->release(s);
         } else {
-            d->ready.wait_on(s);
+            d->ready.edge_wait(s);
         }
         if (n_dest_ == 1) {
             d->ready.record(s);
