@@ -16,6 +16,9 @@
 //   bench_ops_gpu -o <op> [-s sources] [-n operator replicas] [-k keys] [-b batch length] [-t seconds]
 //
 // prints one line:  <op> sources=S replicas=N keys=K batch=B : X tuples/s (Y results/s), elapsed Z s
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -112,7 +115,22 @@ struct TimedGenerator {
     }
 };
 
+// WF_SEGV_TRACE=1: print the faulting address and a backtrace with library names (profilers swallow the default one)
+static void segv_trace(int, siginfo_t* si, void*) {
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    dprintf(2, "SIGSEGV at address %p\n", si->si_addr);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(139);
+}
+
 int main(int argc, char** argv) {
+    if (std::getenv("WF_SEGV_TRACE")) {
+        struct sigaction sa {};
+        sa.sa_sigaction = segv_trace;
+        sa.sa_flags = SA_SIGINFO;
+        sigaction(SIGSEGV, &sa, nullptr);
+    }
     std::string op = "map_stateless";
     size_t sources = 4, replicas = 0, keys = 1 << 14, batch = 1 << 17;
     double seconds = 3.0;
