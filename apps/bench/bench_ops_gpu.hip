@@ -181,18 +181,22 @@ int main(int argc, char** argv) {
     MultiPipe& mp = graph.add_source(*src);
     std::unique_ptr<Basic_Operator> oper;
     const bool disjoint = (replicas == sources);  // lane i carries exactly the keys of replica i
+    // distinct keys a replica can see, plus slack: the device table is twice this, and its size decides the number of
+    // sort passes per batch (one 11-bit pass up to 1024 slots)
+    const size_t keys_per_replica = keys_per_source * sources / (disjoint ? sources : 1);
+    const size_t max_keys = keys_per_replica + keys_per_replica / 4 + 16;
     if (op == "map_stateless") {
         oper = MapGPU_Builder(LookupMap{table.data(), mask}).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "filter_stateless") {
         oper = FilterGPU_Builder(HalfFilter()).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "map_stateful" || op == "keyby") {
         auto b = MapGPU_Builder(RunningAverageMap()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))
-                     .withMaxKeys(keys_per_source * sources / (disjoint ? sources : 1) + 1024);
+                     .withMaxKeys(max_keys);
         if (disjoint && op != "keyby") b.withKeyDisjointLanes();
         oper = b.build_unique();
     } else if (op == "filter_stateful") {
         auto b = FilterGPU_Builder(AboveAverageFilter()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))
-                     .withMaxKeys(keys_per_source * sources / (disjoint ? sources : 1) + 1024);
+                     .withMaxKeys(max_keys);
         if (disjoint) b.withKeyDisjointLanes();
         oper = b.build_unique();
     } else {

@@ -781,8 +781,7 @@ public:
         Batch* out = out_pool_->acquire(s);
         out->host_hdr = in->host_hdr;
         out->count_on_host = false;
-        const uint64_t n_launch = 2 + (upper > 0 ? 3 + sorter_.kernels_per_sort(slot_bits_ + 1) : 0);
-        kernels += n_launch - 1;
+        kernels += 1 + (upper > 0 ? 3 + sorter_.kernels_per_sort(slot_bits_ + 1) : 0);
         if (use_graphs_) {
             const GraphKey key{in->slab, out->slab, upper};
             auto it = graphs_.find(key);
@@ -811,11 +810,13 @@ public:
 
 private:
     void enqueue(Batch* in, Batch* out, size_t upper, hipStream_t s) {
-        WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
+        if (upper == 0) WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
         if (upper > 0) {
             const unsigned grid = grid_for(upper);
+            // also clears the header of the output batch
             hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{});
+                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
+                               out->header(), (uint32_t*)nullptr);
             const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,

@@ -204,7 +204,8 @@ public:
     RadixSorter::Sorted group(Batch* in, hipStream_t s, uint64_t& kernels) {
         const size_t upper = std::max<size_t>(1, in->count_on_host ? in->host_hdr.count : in->capacity);
         hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTupleK>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(),
-                           in->template data<T>(), table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), full_.data(), KeyOfTupleK{});
+                           in->template data<T>(), table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), full_.data(), KeyOfTupleK{},
+                           (BatchHeader*)nullptr, n_long_.data());  // also resets the long-run counter of the batch
         kernels += 1 + sorter_.kernels_per_sort(slot_bits_ + 1);
         return sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
     }
@@ -315,7 +316,6 @@ private:
         hipLaunchKernelGGL((gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>), dim3(lgrid), dim3(gpu::BLOCK_THREADS), lds, s, d->header(),
                            d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
                            ctx_->long_heads(), ctx_->n_long(), lay.second, lay.first, func_);
-        WF_HIP_CHECK(hipMemsetAsync(ctx_->n_long(), 0, sizeof(uint32_t), s));
         this->num_kernels_ += 2;
     }
 

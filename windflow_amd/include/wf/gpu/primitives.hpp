@@ -153,11 +153,17 @@ __device__ __forceinline__ uint32_t key_table_slot(unsigned long long* table, ui
 }
 
 // slot[i] = slot of tuple i's key; idx[i] = i.  KeyFn: uint64_t(const T&)
+// First kernel of a keyed batch: it also clears what the later kernels of the batch accumulate into (the header
+// of the output batch, a counter word) - one launch instead of a memset each.
 template <typename T, typename KeyFn>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     assign_slots_kernel(const BatchHeader* hdr, const T* data, unsigned long long* table, uint32_t mask, uint32_t* slot, uint32_t* idx,
-                        uint32_t* n_failed, KeyFn keyfn) {
+                        uint32_t* n_failed, KeyFn keyfn, BatchHeader* clear_hdr, uint32_t* clear_word) {
     const uint32_t n = hdr->count;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(BatchHeader) / sizeof(uint64_t)) {
+        if (clear_hdr) reinterpret_cast<uint64_t*>(clear_hdr)[threadIdx.x] = 0;
+        if (clear_word && threadIdx.x == 0) *clear_word = 0;
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t s = key_table_slot(table, mask, (unsigned long long)keyfn(data[i]));
         if (s == 0xffffffffu) atomicAdd(n_failed, 1u);
