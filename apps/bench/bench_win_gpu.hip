@@ -1,0 +1,166 @@
+// Throughput of the window operators fed tuple by tuple (the reference's programming model for its GPU window
+// operators: wf/win_seq_gpu.hpp batches fired windows, the tuples reach the operator one at a time from CPU
+// operators).  The reference publishes no numbers for them; this program gives ours, CPU and GPU
+// flavours side by side, on count-based sliding windows with a window sum.
+//
+//   bench_win_gpu -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide]
+//                 [-b windows per GPU batch] [-t seconds]
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <iostream>
+#include <string>
+
+#include <wf/windflow_gpu.hpp>
+
+using namespace wf;
+
+struct tuple_t {
+    size_t key = 0;
+    uint64_t id = 0;
+    uint64_t ts = 0;
+    int64_t value = 0;
+    WF_HOST_DEVICE tuple_t() {}
+    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
+        key = k;
+        id = i;
+        ts = t;
+    }
+};
+struct result_t {
+    size_t key = 0;
+    uint64_t id = 0;
+    uint64_t ts = 0;
+    int64_t value = 0;
+    WF_HOST_DEVICE result_t() {}
+    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
+        key = k;
+        id = i;
+        ts = t;
+    }
+};
+
+// window sum in every flavour the operators accept
+struct SumGPU {
+    __host__ __device__ void operator()(uint64_t, const tuple_t* data, size_t n, result_t* res, char*, size_t) const {
+        int64_t sum = 0;
+        for (size_t i = 0; i < n; i++) sum += data[i].value;
+        res->value = sum;
+    }
+};
+struct Sum2GPU {
+    __host__ __device__ void operator()(uint64_t, const result_t* data, size_t n, result_t* res, char*, size_t) const {
+        int64_t sum = 0;
+        for (size_t i = 0; i < n; i++) sum += data[i].value;
+        res->value = sum;
+    }
+};
+static void sum_nic(uint64_t, const Iterable<tuple_t>& win, result_t& res) {
+    int64_t sum = 0;
+    for (const auto& t : win) sum += t.value;
+    res.value = sum;
+}
+static void sum2_nic(uint64_t, const Iterable<result_t>& win, result_t& res) {
+    int64_t sum = 0;
+    for (const auto& t : win) sum += t.value;
+    res.value = sum;
+}
+static void lift_cpu(const tuple_t& t, result_t& r) { r.value = t.value; }
+static void comb_cpu(const result_t& a, const result_t& b, result_t& out) { out.value = a.value + b.value; }
+struct LiftGPU {
+    __host__ __device__ void operator()(const tuple_t& t, result_t& r) const { r.value = t.value; }
+};
+struct CombGPU {
+    __host__ __device__ void operator()(const result_t& a, const result_t& b, result_t& out) const { out.value = a.value + b.value; }
+};
+
+// keys round-robin inside a per-source key range, progressive ids per key, stops after `seconds`
+struct TimedSource {
+    size_t n_keys, n_sources;
+    uint64_t stop_at_us;
+    std::atomic<uint64_t>* generated;
+    uint64_t seq = 0;
+    bool operator()(tuple_t& t, RuntimeContext& ctx) {
+        const uint64_t s = seq++;
+        t.key = (s % n_keys) * n_sources + ctx.getReplicaIndex();
+        t.id = s / n_keys;
+        t.ts = t.id;
+        t.value = (int64_t)(s & 1023);
+        if ((s & 0xfff) == 0xfff) {
+            generated->fetch_add(0x1000, std::memory_order_relaxed);
+            return current_time_usecs() < stop_at_us;
+        }
+        return true;
+    }
+};
+
+int main(int argc, char** argv) {
+    std::string op = "kf_gpu";
+    size_t sources = 2, replicas = 4, keys = 64, batch = 1024;
+    uint64_t win = 1024, slide = 128;
+    double seconds = 3.0;
+    int c;
+    while ((c = getopt(argc, argv, "o:s:n:k:w:l:b:t:")) != -1) {
+        switch (c) {
+            case 'o': op = optarg; break;
+            case 's': sources = std::strtoull(optarg, nullptr, 10); break;
+            case 'n': replicas = std::strtoull(optarg, nullptr, 10); break;
+            case 'k': keys = std::strtoull(optarg, nullptr, 10); break;
+            case 'w': win = std::strtoull(optarg, nullptr, 10); break;
+            case 'l': slide = std::strtoull(optarg, nullptr, 10); break;
+            case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
+            case 't': seconds = std::atof(optarg); break;
+            default:
+                std::cout << argv[0] << " -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide] "
+                          << "[-b batch] [-t seconds]" << std::endl;
+                return 0;
+        }
+    }
+    const bool needs_gpu = op.find("_gpu") != std::string::npos;
+    if (needs_gpu && gpu::device_count() < 1) {
+        std::cerr << "bench_win_gpu: " << op << " needs a GPU" << std::endl;
+        return 3;
+    }
+    std::atomic<uint64_t> generated{0}, results{0};
+    const size_t keys_per_source = std::max<size_t>(1, keys / sources);
+    PipeGraph graph("bench_" + op, Mode::DETERMINISTIC);  // count-based windows need ordered input
+    const uint64_t t0 = current_time_usecs();
+    TimedSource gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), &generated};
+    auto src = Source_Builder(gen).withName("source").withParallelism(sources).build_unique();
+    MultiPipe& mp = graph.add_source(*src);
+    std::unique_ptr<Basic_Operator> oper;
+    if (op == "kf") {
+        oper = KeyFarm_Builder(sum_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
+    } else if (op == "kf_gpu") {
+        oper = KeyFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).build_unique();
+    } else if (op == "wf_gpu") {
+        oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).build_unique();
+    } else if (op == "pf_gpu") {
+        oper = PaneFarmGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas, 1).withBatch(batch).build_unique();
+    } else if (op == "wmr_gpu") {
+        oper = WinMapReduceGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(std::max<size_t>(2, replicas), 1)
+                   .withBatch(batch).build_unique();
+    } else if (op == "kff") {
+        oper = KeyFFAT_Builder(lift_cpu, comb_cpu).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
+    } else if (op == "kff_gpu") {
+        oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(64 * batch)
+                   .withMaxKeys(keys_per_source * sources + 64).withOutputCapacity(1 << 18).build_unique();
+    } else {
+        std::cerr << "unknown operator " << op << std::endl;
+        return 2;
+    }
+    mp.add(*oper);
+    auto sink = Sink_Builder([&results](std::optional<result_t>& r) {
+                    if (r) results.fetch_add(1, std::memory_order_relaxed);
+                }).withName("sink").withParallelism(1).build_unique();
+    mp.add_sink(*sink);
+    graph.run();
+    const double elapsed = (current_time_usecs() - t0) / 1e6;
+    std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " win=" << win << " slide=" << slide
+              << " batch=" << batch << " : " << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed
+              << " windows/s), elapsed " << elapsed << " s" << std::endl;
+    return 0;
+}

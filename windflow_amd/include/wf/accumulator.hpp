@@ -25,8 +25,8 @@ public:
         result_t& acc = it->second;
         // control fields of the running result are the user function's business
         meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t), acc);
-        delete t;
-        emit(new result_t(acc));
+        tuple_delete(t);
+        emit(tuple_new<result_t>(acc));
     }
 
 private:

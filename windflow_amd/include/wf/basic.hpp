@@ -14,6 +14,8 @@
 #include <tuple>
 #include <type_traits>
 
+#include "rt/tuple_pool.hpp"
+
 // Tuple types used by GPU operators must expose their control-field accessors to
 // device code: mark them WF_HOST_DEVICE (expands to nothing for a host compiler).
 #if defined(__HIPCC__)

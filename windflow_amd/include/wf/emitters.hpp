@@ -57,7 +57,7 @@ public:
         tuple_t* t = untag<tuple_t>(msg);
         const bool mk = is_marker(msg);
         for (size_t i = 0; i + 1 < n_dest_; i++) {
-            tuple_t* c = new tuple_t(*t);
+            tuple_t* c = tuple_new<tuple_t>(*t);
             emit_to(mk ? tag_marker(c) : (void*)c, i);
         }
         emit_to(msg, n_dest_ - 1);
@@ -80,12 +80,12 @@ public:
         if constexpr (meta::split_sig<F>::multi) {
             auto dests = func_(*t);
             if (dests.empty()) {
-                delete t;
+                tuple_delete(t);
                 return;
             }
             for (size_t i = 0; i + 1 < dests.size(); i++) {
                 check((size_t)dests[i]);
-                emit_to(new tuple_t(*t), (size_t)dests[i]);
+                emit_to(tuple_new<tuple_t>(*t), (size_t)dests[i]);
             }
             check((size_t)dests.back());
             emit_to(t, (size_t)dests.back());

@@ -24,20 +24,20 @@ public:
                 emit(t);
             } else {
                 ignored_++;
-                delete t;
+                tuple_delete(t);
             }
         } else if constexpr (mode == 1) {
             std::optional<result_t> out = meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t));
-            delete t;
+            tuple_delete(t);
             if (out)
-                emit(new result_t(std::move(*out)));
+                emit(tuple_new<result_t>(std::move(*out)));
             else
                 ignored_++;
         } else {
             std::optional<result_t*> out = meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t));
-            delete t;
+            tuple_delete(t);
             if (out)
-                emit(*out);
+                emit(tuple_adopt(*out));
             else
                 ignored_++;
         }

@@ -16,7 +16,7 @@ public:
     void svc(void* msg, int) override {
         tuple_t* t = static_cast<tuple_t*>(msg);
         meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t), shipper_);
-        delete t;
+        tuple_delete(t);
     }
 
 private:

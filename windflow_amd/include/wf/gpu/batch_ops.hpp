@@ -92,7 +92,7 @@ public:
         gpu::Batch* b = static_cast<gpu::Batch*>(msg);
         const T* d = b->template data<T>();
         const size_t n = b->host_hdr.count;
-        for (size_t i = 0; i < n; i++) emit(new T(d[i]));
+        for (size_t i = 0; i < n; i++) emit(tuple_new<T>(d[i]));
         b->release_host();
     }
 };
@@ -349,7 +349,7 @@ public:
                 if (staging_ == nullptr) open_staging();
                 staging_->template data<in_t>()[staging_->host_hdr.count++] = *t;
                 staging_->host_hdr.watermark = std::max<uint64_t>(staging_->host_hdr.watermark, ts_of(*t));
-                delete t;
+                tuple_delete(t);
                 if (staging_->host_hdr.count == cfg_.batch_len) {
                     ship(staging_);
                     staging_ = nullptr;

@@ -96,7 +96,7 @@ public:
         const uint64_t min_boundary = (kd.last_lwid >= 0) ? p_.win_len + (uint64_t)kd.last_lwid * p_.slide_len : 0;
         if (ord < wa.initial_id + min_boundary) {
             if (kd.last_lwid >= 0 && !marker) dropped_++;
-            delete t;
+            tuple_delete(t);
             return;
         }
         long last_w;
@@ -107,7 +107,7 @@ public:
             const uint64_t n = rel / p_.slide_len;
             last_w = (long)n;
             if (rel >= n * p_.slide_len + p_.win_len && !marker) {
-                delete t;
+                tuple_delete(t);
                 return;
             }
         }
@@ -127,7 +127,7 @@ public:
             for (auto& w : kd.wins)
                 if (ord >= w.start && ord < w.end) w.result.setControlFields(key, w.gwid, ts_of(*t));
         }
-        delete t;
+        tuple_delete(t);
     }
 
     void flush() override {
@@ -205,7 +205,7 @@ private:
     void drain() {
         if (in_flight_ == 0) return;
         stream_->sync();
-        for (size_t i = 0; i < in_flight_; i++) emit(new result_t(h_res_[i]));
+        for (size_t i = 0; i < in_flight_; i++) emit(tuple_new<result_t>(h_res_[i]));
         in_flight_ = 0;
     }
 

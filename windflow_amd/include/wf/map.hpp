@@ -20,9 +20,9 @@ public:
             meta::invoke_rich(func_, context, *t);
             emit(t);
         } else {
-            result_t* r = new result_t();
+            result_t* r = tuple_new<result_t>();
             meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t), *r);
-            delete t;
+            tuple_delete(t);
             emit(r);
         }
     }

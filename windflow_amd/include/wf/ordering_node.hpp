@@ -49,10 +49,10 @@ public:
             } else {
                 const uint64_t old = (mode_ == ID) ? id_of(*ks.marker) : ts_of(*ks.marker);
                 if (ord > old) {
-                    delete ks.marker;
+                    tuple_delete(ks.marker);
                     ks.marker = t;
                 } else {
-                    delete t;
+                    tuple_delete(t);
                 }
             }
             return;

@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "rt/node.hpp"
+#include "rt/tuple_pool.hpp"
 
 namespace wf {
 
@@ -14,17 +15,18 @@ public:
     explicit Shipper(rt::Node* node) : node_(node) {}
     // copy semantics
     void push(const result_t& r) {
-        node_->emit(new result_t(r));
+        node_->emit(tuple_new<result_t>(r));
         delivered_++;
     }
     // move semantics
     void push(result_t&& r) {
-        node_->emit(new result_t(std::move(r)));
+        node_->emit(tuple_new<result_t>(std::move(r)));
         delivered_++;
     }
-    // ownership transfer of a heap object created with new
+    // ownership transfer of a heap object created with new: tuples on the edges live in the runtime's tuple
+    // pool (rt/tuple_pool.hpp), so the object is moved into a pooled one and the caller's is destroyed here
     void push(result_t* r) {
-        node_->emit(r);
+        node_->emit(tuple_adopt(r));
         delivered_++;
     }
     unsigned long delivered() const { return delivered_; }

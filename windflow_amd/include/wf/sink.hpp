@@ -21,7 +21,7 @@ public:
     void svc(void* msg, int) override {
         tuple_t* t = untag<tuple_t>(msg);
         if (is_marker(msg)) {  // markers never reach user code
-            delete t;
+            tuple_delete(t);
             return;
         }
         if constexpr (meta::sink_sig<F>::by_ref) {
@@ -31,7 +31,7 @@ public:
             std::optional<tuple_t> o = std::move(*t);
             meta::invoke_rich(func_, context, o);
         }
-        delete t;
+        tuple_delete(t);
     }
     void flush() override {
         if constexpr (meta::sink_sig<F>::by_ref) {

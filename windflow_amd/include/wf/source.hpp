@@ -20,7 +20,7 @@ public:
         if constexpr (meta::source_sig<F>::loop) {
             return meta::invoke_rich(func_, context, shipper_);
         } else {
-            tuple_t* t = new tuple_t();
+            tuple_t* t = tuple_new<tuple_t>();
             const bool more = meta::invoke_rich(func_, context, *t);
             emit(t);
             return more;

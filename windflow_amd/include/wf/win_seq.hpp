@@ -79,7 +79,7 @@ public:
         const uint64_t min_boundary = (kd.last_lwid >= 0) ? p_.win_len + (uint64_t)kd.last_lwid * p_.slide_len : 0;
         if (ord < wa.initial_id + min_boundary) {
             if (kd.last_lwid >= 0 && !marker) dropped_++;
-            delete t;
+            tuple_delete(t);
             return;
         }
         // last window containing (or preceding) the tuple
@@ -91,7 +91,7 @@ public:
             const uint64_t n = rel / p_.slide_len;
             last_w = (long)n;
             if (rel >= n * p_.slide_len + p_.win_len && !marker) {  // falls in a gap between hopping windows
-                delete t;
+                tuple_delete(t);
                 return;
             }
         }
@@ -126,7 +126,7 @@ public:
                 if constexpr (!isNIC) meta::invoke_rich(func_, context, w.gwid, static_cast<const tuple_t&>(*t), w.result);
             }
         }
-        delete t;
+        tuple_delete(t);
     }
 
     // end of stream: every window still open is computed and emitted (reference :476-528)
@@ -166,7 +166,7 @@ private:
             kd.archive.purge(w.start + p_.slide_len);
         }
         kd.last_lwid++;
-        result_t* out = new result_t(w.result);
+        result_t* out = tuple_new<result_t>(w.result);
         if (p_.role == MAP) {
             out->setControlFields(key, kd.emit_counter, ts_of(*out));
             kd.emit_counter += p_.map_stride;

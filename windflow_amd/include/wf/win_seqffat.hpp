@@ -48,7 +48,7 @@ public:
     void svc(void* msg, int) override {
         tuple_t* t = untag<tuple_t>(msg);
         if (is_marker(msg)) {  // key-partitioned input: markers carry no information here
-            delete t;
+            tuple_delete(t);
             return;
         }
         const key_t key = key_of(*t);
@@ -65,7 +65,7 @@ public:
             const uint64_t q = ts / quantum_;
             if (q < kd.last_quantum) {
                 dropped_++;
-                delete t;
+                tuple_delete(t);
                 return;
             }
             const uint64_t distance = q - kd.last_quantum;
@@ -101,7 +101,7 @@ public:
             kd.acc.erase(kd.acc.begin(), kd.acc.begin() + (std::ptrdiff_t)done);
             kd.acc_used.erase(kd.acc_used.begin(), kd.acc_used.begin() + (std::ptrdiff_t)done);
         }
-        delete t;
+        tuple_delete(t);
     }
 
     void flush() override {
@@ -166,7 +166,7 @@ private:
         const WinAssign wa(p_.config, std::hash<key_t>()(key), p_.role);
         const uint64_t gwid = wa.first_gwid_key + kd.next_lwid * wa.gwid_stride;
         kd.next_lwid++;
-        result_t* out = new result_t();
+        result_t* out = tuple_new<result_t>();
         kd.fat.getResult(*out);
         kd.fat.remove(slide_q_);
         out->setControlFields(key, gwid, ts_of(*out));

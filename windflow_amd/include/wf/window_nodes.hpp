@@ -49,13 +49,13 @@ public:
             if (ord > last) it->second.last = *t;
         }
         if (is_marker(msg)) {  // markers from upstream only refresh the last tuple
-            delete t;
+            tuple_delete(t);
             return;
         }
         const uint64_t first_gwid_key = (id_outer_ + n_outer_ - (hashcode % n_outer_)) % n_outer_;
         const uint64_t initial_id = (role_ == WLQ || role_ == REDUCE) ? 0 : first_gwid_key * slide_outer_;
         if (ord < initial_id) {
-            delete t;
+            tuple_delete(t);
             return;
         }
         const uint64_t rel = ord - initial_id;
@@ -66,7 +66,7 @@ public:
         } else {
             const uint64_t n = rel / slide_;
             if (rel >= n * slide_ + win_) {  // gap between hopping windows
-                delete t;
+                tuple_delete(t);
                 return;
             }
             first_w = last_w = n;
@@ -77,14 +77,14 @@ public:
         for (uint64_t w = first_w; w <= last_w && sent < n_; w++, sent++) {
             const size_t dst = (start + w) % n_;
             const bool last_copy = (w == last_w) || (sent + 1 == n_);
-            emit_to(last_copy ? t : new tuple_t(*t), dst);
+            emit_to(last_copy ? t : tuple_new<tuple_t>(*t), dst);
         }
     }
 
     void flush() override {
         for (auto& kv : keys_) {
             if (!kv.second.seen) continue;
-            for (size_t i = 0; i < n_; i++) emit_to(tag_marker(new tuple_t(kv.second.last)), i);
+            for (size_t i = 0; i < n_; i++) emit_to(tag_marker(tuple_new<tuple_t>(kv.second.last)), i);
         }
     }
 
@@ -122,7 +122,7 @@ public:
             if (ord > last) it->second.last = *t;
         }
         if (is_marker(msg)) {
-            delete t;
+            tuple_delete(t);
             return;
         }
         emit_to(t, it->second.next);
@@ -130,7 +130,7 @@ public:
     }
     void flush() override {
         for (auto& kv : keys_)
-            for (size_t i = 0; i < n_; i++) emit_to(tag_marker(new tuple_t(kv.second.last)), i);
+            for (size_t i = 0; i < n_; i++) emit_to(tag_marker(tuple_new<tuple_t>(kv.second.last)), i);
     }
 
 private:
@@ -161,7 +161,7 @@ public:
         if (it->second == my_id_)
             emit(t);
         else
-            delete t;
+            tuple_delete(t);
         it->second = (it->second + 1) % n_;
     }
 
