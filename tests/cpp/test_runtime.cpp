@@ -349,6 +349,84 @@ static int illegal(int which) {
     return 0;  // reaching this point means the library accepted the topology
 }
 
+// tuple pool: producers allocate, consumers destroy (the pipeline pattern), blocks are recycled, values survive,
+// destructors run exactly once, over-aligned / large types fall back to the heap
+struct Tracked {
+    static std::atomic<long> alive;
+    long v;
+    std::string s;
+    explicit Tracked(long x) : v(x), s("tuple " + std::to_string(x)) { alive++; }
+    Tracked(Tracked&& o) : v(o.v), s(std::move(o.s)) { alive++; }
+    Tracked(const Tracked& o) : v(o.v), s(o.s) { alive++; }
+    ~Tracked() { alive--; }
+};
+std::atomic<long> Tracked::alive{0};
+struct alignas(64) OverAligned {
+    long v;
+};
+struct Huge {
+    char bytes[8192];
+};
+
+static void test_tuple_pool() {
+    static_assert(mem::poolable<Tracked>, "small types are pooled");
+    static_assert(!mem::poolable<OverAligned> && !mem::poolable<Huge>, "these go to the heap");
+    constexpr long N = 200000;
+    constexpr int PAIRS = 3;
+    std::vector<std::unique_ptr<rt::SPSCQueue>> qs;
+    for (int i = 0; i < PAIRS; i++) qs.emplace_back(new rt::SPSCQueue(256));
+    std::atomic<long> sum{0};
+    std::vector<std::thread> th;
+    for (int i = 0; i < PAIRS; i++) {
+        th.emplace_back([&, i] {
+            for (long k = 0; k < N; k++) {
+                Tracked* t = tuple_new<Tracked>(k);
+                while (!qs[i]->try_push(t)) std::this_thread::yield();
+            }
+        });
+        th.emplace_back([&, i] {
+            long local = 0;
+            for (long k = 0; k < N; k++) {
+                void* p = nullptr;
+                while (!qs[i]->try_pop(p)) std::this_thread::yield();
+                Tracked* t = static_cast<Tracked*>(p);
+                if (t->s != "tuple " + std::to_string(t->v)) local -= 1000000;
+                local += t->v;
+                tuple_delete(t);
+            }
+            sum += local;
+        });
+    }
+    for (auto& t : th) t.join();
+    CHECK(sum.load() == PAIRS * (N * (N - 1) / 2));
+    CHECK(Tracked::alive.load() == 0);
+    // same thread, interleaved lifetimes across block boundaries
+    std::vector<Tracked*> held;
+    for (long k = 0; k < 5000; k++) {
+        held.push_back(tuple_new<Tracked>(k));
+        if (k % 3 == 0) {
+            tuple_delete(held.front());
+            held.erase(held.begin());
+        }
+    }
+    long s2 = 0;
+    for (Tracked* t : held) {
+        s2 += t->v;
+        tuple_delete(t);
+    }
+    CHECK(s2 > 0 && Tracked::alive.load() == 0);
+    OverAligned* oa = tuple_new<OverAligned>();
+    CHECK(reinterpret_cast<uintptr_t>(oa) % 64 == 0);
+    tuple_delete(oa);
+    tuple_delete(tuple_new<Huge>());
+    // a user-allocated object handed over is moved into a pooled one
+    Tracked* mine = new Tracked(77);
+    Tracked* adopted = tuple_adopt(mine);
+    CHECK(adopted->v == 77 && adopted->s == "tuple 77" && Tracked::alive.load() == 1);
+    tuple_delete(adopted);
+    CHECK(Tracked::alive.load() == 0);
+}
+
 int main(int argc, char** argv) {
     if (argc == 3 && strcmp(argv[1], "illegal") == 0) return illegal(atoi(argv[2]));
     test_spsc();
@@ -357,6 +435,7 @@ int main(int argc, char** argv) {
     test_flatfat();
     test_stats_and_dot();
     test_dropped_tuples();
+    test_tuple_pool();
     cout << (failures == 0 ? "ALL OK" : "FAILED") << endl;
     return failures == 0 ? 0 : 1;
 }
