@@ -206,9 +206,20 @@ inline bool d2h_shared_stream() {
     return h;
 }
 
+// Host waits on events sleep in the driver instead of spinning: the waiting threads (one per lane) leave their
+// cores to the sources and sinks, at no measurable cost in throughput or latency (profiles/r1_sync_policy).
+// WF_EVENT_BLOCKING=0 selects spinning waits.
+inline bool event_blocking_sync() {
+    static const bool b = [] {
+        const char* e = std::getenv("WF_EVENT_BLOCKING");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return b;
+}
+
 class Event {
 public:
-    Event() { WF_HIP_CHECK(hipEventCreateWithFlags(&e_, hipEventDisableTiming)); }
+    Event() { WF_HIP_CHECK(hipEventCreateWithFlags(&e_, hipEventDisableTiming | (event_blocking_sync() ? hipEventBlockingSync : 0))); }
     ~Event() {
         if (e_) (void)hipEventDestroy(e_);
     }
