@@ -115,6 +115,19 @@ struct TimedGenerator {
     }
 };
 
+// the same stream generated on the device (-d): no host->device copies, shows what the operators sustain when the
+// data is already in HBM
+struct DeviceGenerator {
+    uint64_t n_keys, n_sources;
+    __host__ __device__ void operator()(uint64_t s, uint32_t src, tuple_t& t) const {
+        t.key = (s % n_keys) * n_sources + src;
+        t.id = s / n_keys;
+        t.ts = s;
+        t.value = (double)((s * 2654435761ull >> 7) & 1023);
+        t.aux = 0.0;
+    }
+};
+
 // WF_SEGV_TRACE=1: print the faulting address and a backtrace with library names (profilers swallow the default one)
 static void segv_trace(int, siginfo_t* si, void*) {
     void* frames[48];
@@ -134,8 +147,9 @@ int main(int argc, char** argv) {
     std::string op = "map_stateless";
     size_t sources = 4, replicas = 0, keys = 1 << 14, batch = 1 << 17;
     double seconds = 3.0;
+    bool device_source = false;
     int c;
-    while ((c = getopt(argc, argv, "o:s:n:k:b:t:")) != -1) {
+    while ((c = getopt(argc, argv, "o:s:n:k:b:t:d")) != -1) {
         switch (c) {
             case 'o': op = optarg; break;
             case 's': sources = std::strtoull(optarg, nullptr, 10); break;
@@ -143,9 +157,10 @@ int main(int argc, char** argv) {
             case 'k': keys = std::strtoull(optarg, nullptr, 10); break;
             case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
             case 't': seconds = std::atof(optarg); break;
+            case 'd': device_source = true; break;
             default:
-                std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|filter_stateful|keyby [-s sources] [-n replicas] "
-                          << "[-k keys] [-b batch] [-t seconds]" << std::endl;
+                std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|filter_stateful|keyby|win_agg [-s sources] [-n replicas] "
+                          << "[-k keys] [-b batch] [-t seconds] [-d (generate on the device)]" << std::endl;
                 return 0;
         }
     }
@@ -177,7 +192,23 @@ int main(int argc, char** argv) {
     PipeGraph graph("bench_" + op, Mode::DEFAULT);
     const uint64_t t0 = current_time_usecs();
     TimedGenerator gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), 0, &generated};
-    auto src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).build_unique();
+    std::unique_ptr<Basic_Operator> src;
+    if (device_source) {
+        const uint64_t stop_at = t0 + (uint64_t)(seconds * 1e6);
+        auto* gcount = &generated;
+        src = DeviceSource_Builder(DeviceGenerator{keys_per_source, sources})
+                  .withName("device_source")
+                  .withParallelism(sources)
+                  .withBatch(batch)
+                  .withStopCondition([stop_at, gcount, batch](uint64_t) {
+                      if (current_time_usecs() >= stop_at) return false;
+                      gcount->fetch_add(batch, std::memory_order_relaxed);
+                      return true;
+                  })
+                  .build_unique();
+    } else {
+        src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).build_unique();
+    }
     MultiPipe& mp = graph.add_source(*src);
     std::unique_ptr<Basic_Operator> oper;
     const bool disjoint = (replicas == sources);  // lane i carries exactly the keys of replica i
@@ -199,17 +230,39 @@ int main(int argc, char** argv) {
                      .withMaxKeys(max_keys);
         if (disjoint) b.withKeyDisjointLanes();
         oper = b.build_unique();
+    } else if (op == "win_agg") {
+        // the flagship of bench.py: keyed sliding-window sum, time-based window of 16 / slide of 4 tuples of a key
+        if (!disjoint) {
+            std::cerr << "win_agg needs as many replicas as sources" << std::endl;
+            return 2;
+        }
+        KeyFFATGPUConfig wcfg;
+        wcfg.win_len = 16 * keys_per_source;
+        wcfg.slide_len = 4 * keys_per_source;
+        wcfg.delay = 0;
+        wcfg.type = TB;
+        wcfg.max_keys = keys_per_source;
+        wcfg.out_capacity = batch;
+        wcfg.lanes_are_key_disjoint = true;
+        GPUConfig cfg;
+        cfg.batch_len = batch;
+        oper.reset(new Key_FFAT_GPU<tuple_t, wfbench::result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, replicas, "key_ffat_gpu", cfg));
     } else {
         std::cerr << "unknown operator " << op << std::endl;
         return 2;
     }
     mp.add(*oper);
-    auto sink = BatchSink_Builder([&results](const tuple_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
-                    .withName("sink").withParallelism(replicas).build_unique();
+    std::unique_ptr<Basic_Operator> sink;
+    if (op == "win_agg")
+        sink = BatchSink_Builder([&results](const wfbench::result_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
+                   .withName("sink").withParallelism(replicas).build_unique();
+    else
+        sink = BatchSink_Builder([&results](const tuple_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
+                   .withName("sink").withParallelism(replicas).build_unique();
     mp.chain_sink(*sink);
     graph.run();
     const double elapsed = (current_time_usecs() - t0) / 1e6;
-    std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " batch=" << batch << " : "
+    std::cout << op << (device_source ? " [device source]" : "") << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " batch=" << batch << " : "
               << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed << " results/s), elapsed " << elapsed
               << " s" << std::endl;
     return 0;

@@ -248,6 +248,51 @@ int main(int argc, char** argv) {
              << (ok ? "  OK" : "  FAILED") << endl;
         failures += !ok;
     }
+    // ---- F: the stream is born on the device (Device_Source): 2 source replicas -> device KeyBy -> keyed Map_GPU ----
+    for (size_t run = 0; run < runs; run++) {
+        struct DevGen {
+            uint64_t keys;
+            __host__ __device__ void operator()(uint64_t seq, uint32_t replica, tuple_t& t) const {
+                t.key = (size_t)((seq % keys) * 2 + replica);
+                t.id = seq;
+                t.ts = seq;
+                t.value = (int64_t)((seq * 7 + replica * 3) % 17) - 8;
+            }
+        };
+        const size_t p1 = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        const uint64_t per_replica = ((n / 2 + batch - 1) / batch) * batch;  // whole batches
+        long exp_sum = 0;
+        {
+            DevGen g{keys};
+            map<size_t, int64_t> acc;
+            for (uint32_t r = 0; r < 2; r++)
+                for (uint64_t q = 0; q < per_replica; q++) {
+                    tuple_t t;
+                    g(q, r, t);
+                    acc[t.key] += t.value;
+                    exp_sum += acc[t.key];
+                }
+        }
+        PipeGraph g("device_source", Mode::DEFAULT);
+        auto src = DeviceSource_Builder(DevGen{keys}).withName("dsrc").withParallelism(2).withBatch(batch).withLimit(per_replica).build_unique();
+        MultiPipe& mp = g.add_source(*src);
+        auto map = MapGPU_Builder(RunningSum()).withName("kmap").withParallelism(p1).withScratchpad(16).withMaxKeys(2 * keys + 2).build_unique();
+        mp.add(*map);
+        long sum = 0, cnt = 0;
+        Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                        if (o) {
+                            sum += o->value;
+                            cnt++;
+                        }
+                    }).withParallelism(1).build();
+        mp.add_sink(sink);
+        g.run();
+        const bool ok = (sum == exp_sum && cnt == (long)(2 * per_replica));
+        cout << "F device source par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << exp_sum << " "
+             << 2 * per_replica << ")" << (ok ? "  OK" : "  FAILED") << endl;
+        failures += !ok;
+    }
     // ---- E (only with 2+ GPUs): scenario B with the replicas of the two keyed operators placed on different GPUs; the
     //      sub-batches of the device KeyBy cross GPUs with peer copies ----
     // opt-in (WF_TEST_MULTI_GPU=1): this path has not run on real multi-GPU hardware yet

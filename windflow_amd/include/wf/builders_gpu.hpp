@@ -193,6 +193,34 @@ private:
     F func_;
 };
 
+// Device_Source: generator __host__ __device__ void(uint64_t seq, uint32_t replica, tuple_t&)
+template <typename G>
+class DeviceSource_Builder : public GPU_Builder_Base<DeviceSource_Builder<G>> {
+public:
+    using tuple_t = meta::arg_bare_t<G, 2>;
+    using source_t = Device_Source<tuple_t>;
+    explicit DeviceSource_Builder(G gen) : GPU_Builder_Base<DeviceSource_Builder<G>>("device_source"), gen_(gen) {}
+    // stop after this many tuples per replica (rounded up to whole batches)
+    DeviceSource_Builder& withLimit(uint64_t tuples_per_replica) {
+        more_ = [tuples_per_replica](uint64_t seq) { return seq < tuples_per_replica; };
+        return *this;
+    }
+    // asked before every batch with the number of tuples generated so far by the replica
+    DeviceSource_Builder& withStopCondition(std::function<bool(uint64_t)> more) {
+        more_ = std::move(more);
+        return *this;
+    }
+    source_t* build_ptr() {
+        if (!more_) fatal_error("DeviceSource_Builder: withLimit() or withStopCondition() is required");
+        return new source_t(gen_, more_, this->parallelism_, this->name_, this->cfg_.batch_len, this->cfg_.pool_slabs, this->cfg_, this->closing_);
+    }
+    std::unique_ptr<source_t> build_unique() { return std::unique_ptr<source_t>(build_ptr()); }
+
+private:
+    G gen_;
+    std::function<bool(uint64_t)> more_;
+};
+
 template <typename F>
 class BatchSink_Builder : public Builder_Base<BatchSink_Builder<F>> {
 public:

@@ -271,6 +271,98 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<tuple_t>(); }
 };
 
+// ---- Device_Source ------------------------------------------------------------
+// A source whose tuples are born in device memory (synthetic load, replay of device-resident data, a NIC that
+// writes into HBM): no host->device copy, the stream enters the pipeline as device batches.  The generator is a
+// pure function of the replica and of the replica-local sequence number,
+//     __host__ __device__ void(uint64_t seq, uint32_t replica, tuple_t& t)
+// evaluated by one thread per tuple; the host decides when to stop: `more(seq)` is asked before every batch.
+// The reference has no counterpart (its GPU operators are always fed from host memory).
+namespace gpu {
+template <typename T, typename G>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    device_source_kernel(BatchHeader* hdr, T* data, uint64_t first_seq, uint32_t n, uint32_t replica, BatchHeader host_view, G gen) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        T t{};
+        gen(first_seq + i, replica, t);
+        data[i] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = host_view;
+}
+}  // namespace gpu
+
+template <typename tuple_t, typename G>
+class Device_Source_Node : public Replica_Base {
+    static_assert(std::is_trivially_copyable_v<tuple_t>, "batched tuples are raw bytes: they must be trivially copyable");
+
+public:
+    Device_Source_Node(G gen, std::function<bool(uint64_t)> more, size_t batch_len, size_t slabs, int device, std::string name, size_t par,
+                       size_t idx, meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), false, true), gen_(gen), more_(std::move(more)),
+          batch_len_(batch_len), slabs_(slabs), device_(device) {
+        set_io_bytes(0, sizeof(tuple_t) * batch_len);
+    }
+    bool is_source() const override { return true; }
+    void svc_init() override {
+        Replica_Base::svc_init();
+        WF_HIP_CHECK(hipSetDevice(device_));
+        stream_.reset(new gpu::Stream());
+        pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, device_, sizeof(tuple_t), batch_len_, slabs_));
+    }
+    bool generate() override {
+        if (!more_(seq_)) return false;
+        gpu::Batch* d = pool_->acquire(stream_->get());
+        const uint32_t replica = (uint32_t)context.getReplicaIndex();
+        d->host_hdr.count = (uint32_t)batch_len_;
+        d->host_hdr.source_id = replica;
+        d->host_hdr.first_seq = seq_;
+        d->host_hdr.created_ns = current_time_nsecs();
+        tuple_t last{};
+        gen_(seq_ + batch_len_ - 1, replica, last);  // the generator runs on the host too: the watermark is known here
+        d->host_hdr.watermark = ts_of(last);
+        d->count_on_host = true;
+        hipLaunchKernelGGL((gpu::device_source_kernel<tuple_t, G>), dim3(gpu::grid_for(batch_len_)), dim3(gpu::BLOCK_THREADS), 0, stream_->get(),
+                           d->header(), d->template data<tuple_t>(), seq_, (uint32_t)batch_len_, replica, d->host_hdr, gen_);
+        WF_HIP_CHECK(hipGetLastError());
+        d->ready.record(stream_->get());
+        kernels_++;
+        seq_ += batch_len_;
+        emit(d);
+        return true;
+    }
+    void svc_end() override {
+        if (stream_) stream_->sync();
+        Replica_Base::svc_end();
+    }
+
+protected:
+    void finalize_stats(Stats_Record& s) override { s.num_kernels = kernels_; }
+
+private:
+    G gen_;
+    std::function<bool(uint64_t)> more_;
+    size_t batch_len_, slabs_;
+    int device_;
+    uint64_t seq_ = 0, kernels_ = 0;
+    std::unique_ptr<gpu::Stream> stream_;
+    std::unique_ptr<gpu::BatchPool> pool_;
+};
+
+template <typename tuple_t>
+class Device_Source : public Simple_Operator<void, tuple_t> {
+public:
+    template <typename G>
+    Device_Source(G gen, std::function<bool(uint64_t)> more, size_t parallelism, std::string name, size_t batch_len, size_t slabs = 6,
+                  GPUConfig cfg = GPUConfig(), meta::closing_func_t closing = nullptr)
+        : Simple_Operator<void, tuple_t>(name, parallelism, NONE, nullptr,
+                                         [=](size_t i, size_t n, std::shared_ptr<StatsHub> hub) -> rt::Node* {
+                                             return new Device_Source_Node<tuple_t, G>(gen, more, batch_len, slabs, cfg.device_for(i), name, n, i,
+                                                                                      closing, std::move(hub));
+                                         }) {}
+    edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<tuple_t>(); }
+};
+
 // ---- Batch_Sink --------------------------------------------------------------
 // Functor: void(const tuple_t* data, size_t n) or
 //          void(const tuple_t* data, size_t n, const gpu::BatchHeader&)  [+ RuntimeContext&];
