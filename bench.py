@@ -32,6 +32,9 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--drain-every-step", action="store_true",
+                   help="wait for every step's results before feeding the next one (default: the K timed steps are streamed "
+                        "back to back and the timed region ends when the last one has drained)")
     p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "win_agg"),
                    help="win_agg: keyed sliding-window aggregation (flagship); map_filter: stateless Map_GPU+Filter_GPU")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
@@ -113,12 +116,17 @@ def rank_cpus(local_rank, world):
     return allowed[local_rank * per:(local_rank + 1) * per] if per >= 8 else allowed
 
 
-def timed_steps(pipe, per_source, steps, barrier):
+def timed_steps(pipe, per_source, steps, barrier, drain_every_step=False):
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.step(per_source)
+    if drain_every_step:
+        for _ in range(steps):
+            pipe.step(per_source)
+    else:
+        # a stream has no step boundaries: the K steps are fed back to back and the call returns when the results of
+        # the last one have reached the sinks (one pipeline drain inside the timed region instead of K)
+        pipe.steps(steps, per_source)
     torch.cuda.synchronize()
     barrier()
     return time.perf_counter() - t0
@@ -236,7 +244,7 @@ def main():
     for _ in range(args.warmup):
         pipe.step(per_source)
     pipe.reset_latency()
-    elapsed = timed_steps(pipe, per_source, args.steps, barrier)
+    elapsed = timed_steps(pipe, per_source, args.steps, barrier, args.drain_every_step)
     stats = pipe.stats()
     pipe.close()
     t = torch.tensor([elapsed], dtype=torch.float64)
@@ -280,6 +288,7 @@ def main():
                 "sources_per_gpu": args.sources,
                 "keys_per_gpu": keys_per_source * args.sources,
                 "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if args.count_based else "TB", args.win, args.slide),
+                "steps_streamed": "drained after every step" if args.drain_every_step else "back to back, drained once at the end of the timed region",
                 "sink_results_rank0": stats["sink_tuples"],
                 "overflow": stats.get("overflow", 0),
                 "dropped": stats.get("dropped", 0),

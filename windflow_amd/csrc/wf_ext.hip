@@ -142,6 +142,13 @@ public:
         for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
         barrier_->wait(step_id_, (int)n_sources_);
     }
+    // k steps streamed back to back (no drain between them): returns when the last one has reached the sinks
+    void steps(int64_t k, int64_t tuples_per_source) {
+        py::gil_scoped_release rel;
+        step_id_ += (uint64_t)k;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, k * tuples_per_source);
+        barrier_->wait(step_id_, (int)n_sources_);
+    }
     void close() {
         if (closed_) return;
         closed_ = true;
@@ -343,6 +350,13 @@ public:
         for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
         barrier_->wait(step_id_, (int)n_sinks_);
     }
+    // k steps streamed back to back (no drain between them): returns when the last one has reached the sinks
+    void steps(int64_t k, int64_t tuples_per_source) {
+        py::gil_scoped_release rel;
+        step_id_ += (uint64_t)k;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, k * tuples_per_source);
+        barrier_->wait(step_id_, (int)n_sinks_);
+    }
     void close() {
         if (closed_) return;
         closed_ = true;
@@ -510,6 +524,7 @@ PYBIND11_MODULE(_C, m) {
              py::arg("time_based") = false, py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr,
              py::arg("agg_replicas") = 0)
         .def("step", &WinAggPipeline::step)
+        .def("steps", &WinAggPipeline::steps)
         .def("close", &WinAggPipeline::close)
         .def("stats", &WinAggPipeline::stats)
         .def("reset_latency", &WinAggPipeline::reset_latency)
@@ -518,6 +533,7 @@ PYBIND11_MODULE(_C, m) {
         .def(py::init<int, size_t, size_t, size_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"),
              py::arg("inflight") = 6)
         .def("step", &MapFilterPipeline::step)
+        .def("steps", &MapFilterPipeline::steps)
         .def("close", &MapFilterPipeline::close)
         .def("stats", &MapFilterPipeline::stats)
         .def("reset_latency", &MapFilterPipeline::reset_latency)
