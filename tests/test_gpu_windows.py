@@ -21,7 +21,8 @@ def test_exclusive_scan_matches_torch(ext, n):
     assert torch.equal(out.cpu().to(torch.int64), ref)
 
 
-@pytest.mark.parametrize("n,bits", [(1, 8), (1000, 8), (2049, 11), (100_000, 17), (1_000_000, 21), (300_000, 32)])
+@pytest.mark.parametrize("n,bits", [(1, 8), (1000, 8), (2049, 11), (20_000, 16), (30_000, 17), (32_768, 22), (32_769, 11), (40_000, 8),
+                                    (100_000, 17), (1_000_000, 21), (300_000, 32)])
 def test_radix_sort_pairs_is_stable_and_sorted(ext, n, bits):
     g = torch.Generator().manual_seed(bits * 7 + n)
     hi = (1 << bits) if bits < 31 else (1 << 31) - 1

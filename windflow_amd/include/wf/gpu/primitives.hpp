@@ -196,6 +196,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     hist[threadIdx.x * n_tiles + tile] = s_hist[threadIdx.x];
 }
 
+// RAW: `hist_scanned` holds the raw per-tile counts and `bin_totals` is not read - every block derives the bin
+// totals and its own offsets inside the bins from them.  For batches of a few tiles that is cheaper than the
+// launch of the scan kernel between the histogram and the scatter (RadixSorter::FUSE_TILES).
+template <bool RAW>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     radix_scatter_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
                          uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
@@ -204,9 +208,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     __shared__ uint32_t s_cnt[RS_ITEMS * NW][RS_BINS];  // per (item round, wave) digit counts -> 32 KiB
     __shared__ uint32_t s_bin_base[RS_BINS];
     __shared__ uint32_t s_wsum[NW];
+    uint32_t tile_off = 0;  // tuples of this thread's digit in the tiles before this one
     {
         // exclusive scan of the 256 bin totals (one value per thread)
-        const uint32_t v = bin_totals[threadIdx.x];
+        uint32_t v = 0;
+        if constexpr (RAW) {
+            for (uint32_t t = 0; t < n_tiles; t++) {
+                const uint32_t c = hist_scanned[threadIdx.x * n_tiles + t];
+                if (t < blockIdx.x) tile_off += c;
+                v += c;
+            }
+        } else {
+            v = bin_totals[threadIdx.x];
+            tile_off = hist_scanned[threadIdx.x * n_tiles + blockIdx.x];
+        }
         const uint32_t inc = wave_inclusive_scan(v);
         if (lane_id() == WAVE - 1) s_wsum[wave_id()] = inc;
         __syncthreads();
@@ -242,7 +257,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     __syncthreads();
     // per digit (one thread per digit): exclusive prefix over the (round, wave) sequence + global base
     {
-        uint32_t run = s_bin_base[threadIdx.x] + hist_scanned[threadIdx.x * n_tiles + tile];
+        uint32_t run = s_bin_base[threadIdx.x] + tile_off;
         for (int r = 0; r < RS_ITEMS * NW; r++) {
             const uint32_t c = s_cnt[r][threadIdx.x];
             s_cnt[r][threadIdx.x] = run;
@@ -315,6 +330,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     for (int b = threadIdx.x; b < RSW_BINS; b += BLOCK_THREADS) hist[(size_t)b * n_tiles + tile] = s_hist[b];
 }
 
+template <bool RAW>  // see radix_scatter_kernel
 __global__ void __launch_bounds__(BLOCK_THREADS)
     radix_scatter_wide_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
                               uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
@@ -323,6 +339,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     constexpr int PER_THREAD = RSW_BINS / BLOCK_THREADS;  // bins whose global base a thread computes
     __shared__ uint32_t s_cnt[NW][RSW_BINS];               // per-wave running digit counters, then offsets (32 KiB)
     __shared__ uint32_t s_bin_base[RSW_BINS];
+    __shared__ uint32_t s_tile_off[RAW ? RSW_BINS : 1];    // RAW: tuples of a digit in the tiles before this one
     __shared__ uint32_t s_wsum[NW];
     const int lane = lane_id(), wave = wave_id();
     {
@@ -331,7 +348,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         uint32_t sum = 0;
 #pragma unroll
         for (int q = 0; q < PER_THREAD; q++) {
-            local[q] = bin_totals[threadIdx.x * PER_THREAD + q];
+            const uint32_t bin = threadIdx.x * PER_THREAD + q;
+            if constexpr (RAW) {
+                uint32_t tot = 0, before = 0;
+                for (uint32_t t = 0; t < n_tiles; t++) {
+                    const uint32_t c = hist_scanned[(size_t)bin * n_tiles + t];
+                    if (t < blockIdx.x) before += c;
+                    tot += c;
+                }
+                local[q] = tot;
+                s_tile_off[bin] = before;
+            } else {
+                local[q] = bin_totals[bin];
+            }
             sum += local[q];
         }
         const uint32_t inc = wave_inclusive_scan(sum);
@@ -386,7 +415,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     __syncthreads();
     // per digit: exclusive prefix over the waves + global base of the digit + offset of this tile inside the digit
     for (int d = threadIdx.x; d < RSW_BINS; d += BLOCK_THREADS) {
-        uint32_t run = s_bin_base[d] + hist_scanned[(size_t)d * n_tiles + tile];
+        uint32_t run = s_bin_base[d];
+        if constexpr (RAW)
+            run += s_tile_off[d];
+        else
+            run += hist_scanned[(size_t)d * n_tiles + tile];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             const uint32_t c = s_cnt[w][d];
@@ -445,25 +478,39 @@ public:
         uint32_t* kout = keys_tmp_.data();
         uint32_t* vout = vals_tmp_.data();
         const int d = digit_bits(bits), n_pass = passes(bits);
+        // small batches (latency-oriented pipelines) are launch-bound: two launches per pass instead of three
+        const bool fused = tiles <= FUSE_TILES;
         for (int p = 0; p < n_pass; p++) {
             const int shift = d * p;
             if (d == 8) {
                 hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
-                hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
-                hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
-                                   hist_.data(), bin_totals_.data());
+                if (fused) {
+                    hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles,
+                                       shift, hist_.data(), bin_totals_.data());
+                } else {
+                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                    hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles,
+                                       shift, hist_.data(), bin_totals_.data());
+                }
             } else {
                 hipLaunchKernelGGL(radix_hist_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
-                hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RSW_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
-                hipLaunchKernelGGL(radix_scatter_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles, shift,
-                                   hist_.data(), bin_totals_.data());
+                if (fused) {
+                    hipLaunchKernelGGL(radix_scatter_wide_kernel<true>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev,
+                                       tiles, shift, hist_.data(), bin_totals_.data());
+                } else {
+                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RSW_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                    hipLaunchKernelGGL(radix_scatter_wide_kernel<false>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev,
+                                       tiles, shift, hist_.data(), bin_totals_.data());
+                }
             }
             std::swap(kin, kout);
             std::swap(vin, vout);
         }
         return {kin, vin};
     }
-    int kernels_per_sort(int bits) const { return 3 * passes(bits); }
+    int kernels_per_sort(int bits) const { return 3 * passes(bits); }  // upper bound (2 per pass for small batches)
+    // batches of at most this many tiles (2048 pairs each) skip the scan kernel: the scatter blocks read the raw counts
+    static constexpr uint32_t FUSE_TILES = 16;
 
 private:
     size_t cap_ = 0, tiles_ = 0;
