@@ -199,6 +199,7 @@ public:
         : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub)), func_(std::move(func)), batch_len_(batch_len),
           slabs_(slabs), device_(device) {
         set_io_bytes(0, sizeof(tuple_t) * batch_len);
+        gpu::preload_module(device_);
     }
     bool is_source() const override { return true; }
     void svc_init() override {
@@ -301,6 +302,7 @@ public:
         : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), false, true), gen_(gen), more_(std::move(more)),
           batch_len_(batch_len), slabs_(slabs), device_(device) {
         set_io_bytes(0, sizeof(tuple_t) * batch_len);
+        gpu::preload_module(device_);
     }
     bool is_source() const override { return true; }
     void svc_init() override {
@@ -425,6 +427,7 @@ public:
                 std::shared_ptr<StatsHub> hub, bool is_win = false)
         : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), is_win, true), cfg_(cfg), in_kind_(in_kind) {
         cfg_.gpu_id = cfg.device_for(idx);
+        gpu::preload_module(cfg_.gpu_id);
     }
 
     void svc_init() override {

@@ -143,6 +143,47 @@ private:
     hipStream_t s_ = nullptr;
 };
 
+// HIP loads a binary's device code lazily, at the first launch, and its own copy / fill kernels at the first
+// hipMemcpy / hipMemset.  The lanes of a pipeline start together, so those first uses would race each other - which
+// is harmless for HIP itself but crashes inside rocprofv3's code-object tracking (seen with ROCm 7.2: SIGSEGV in
+// librocprofiler-sdk under the first hipLaunchKernel of several threads).  Every GPU node therefore calls
+// preload_module(device) from its constructor (the graph is built by one thread): one probe launch, one fill and
+// one copy per device, serialised by a mutex, before any lane thread exists.
+__global__ void wf_probe_kernel(uint32_t* p) {
+    if (p != nullptr && threadIdx.x == 0) *p += 1u;
+}
+
+inline void preload_module(int device) {
+    static std::mutex m;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> l(m);
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) return;  // reported where the device is first used
+    if ((size_t)device >= done.size()) done.resize((size_t)device + 1, 0);
+    if (done[(size_t)device]) return;
+    int prev = 0;
+    WF_HIP_CHECK(hipGetDevice(&prev));
+    WF_HIP_CHECK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    WF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    uint32_t* buf = nullptr;
+    uint32_t* host = nullptr;
+    WF_HIP_CHECK(hipMalloc((void**)&buf, 2 * 256));
+    WF_HIP_CHECK(hipHostMalloc((void**)&host, 256, hipHostMallocDefault));
+    WF_HIP_CHECK(hipMemsetAsync(buf, 0, 2 * 256, s));
+    hipLaunchKernelGGL(wf_probe_kernel, dim3(1), dim3(64), 0, s, buf);
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipMemcpyAsync(buf + 64, buf, 256, hipMemcpyDeviceToDevice, s));
+    WF_HIP_CHECK(hipMemcpyAsync(host, buf, 256, hipMemcpyDeviceToHost, s));
+    WF_HIP_CHECK(hipMemcpyAsync(buf, host, 256, hipMemcpyHostToDevice, s));
+    WF_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(buf);
+    (void)hipHostFree(host);
+    (void)hipStreamDestroy(s);
+    WF_HIP_CHECK(hipSetDevice(prev));
+    done[(size_t)device] = 1;
+}
+
 // Streams and hardware queues.  The streams of a process are spread over a few hardware queues (4 by default,
 // GPU_MAX_HW_QUEUES); streams that share a queue run their kernels one after the other, and a stream that waits
 // ON THE DEVICE for an event of another stream parks a barrier packet that holds up every other stream of its

@@ -137,6 +137,7 @@ public:
     KeyBy_EmitterGPU(size_t n_dest, edge_kind_t in_kind, int device, size_t pool_slabs)
         : n_dest_(n_dest), in_kind_(in_kind), device_(device), slabs_(pool_slabs), part_(n_dest, device, pool_slabs) {
         for (size_t i = 0; i < n_dest_; i++) add_out_port();
+        gpu::preload_module(device_);
     }
     void svc_init() override {
         WF_HIP_CHECK(hipSetDevice(device_));

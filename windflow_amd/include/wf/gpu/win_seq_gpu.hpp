@@ -66,6 +66,7 @@ public:
         if (p_.win_len == 0 || p_.slide_len == 0) fatal_error("window length or slide cannot be zero");
         if (cfg_g_.batch_len == 0) fatal_error("batch length cannot be zero");
         cfg_g_.gpu_id = cfg.device_for(idx);
+        gpu::preload_module(cfg_g_.gpu_id);
         set_io_bytes(sizeof(tuple_t), sizeof(result_t));
     }
 
