@@ -86,6 +86,14 @@ def test_ops_key_ffat_and_model_pipeline():
         m.step(10_000)
         st = m.stats()
     assert st["sink_tuples"] == sum(1 for s in range(2) for q in range(10_000) if (q & 1023) * 2 + 1 < 1024)
+    # k steps streamed back to back produce what k drained steps produce
+    with models.WinAgg(gpu_id=0, sources=2, batch=4096, keys_per_source=32, win=8, slide=2, inflight=4) as a:
+        for _ in range(3):
+            a.step(20_000)
+    with models.WinAgg(gpu_id=0, sources=2, batch=4096, keys_per_source=32, win=8, slide=2, inflight=4) as b:
+        b.steps(3, 20_000)
+    sa, sb = a.stats(), b.stats()
+    assert sa["sink_tuples"] == sb["sink_tuples"] > 0 and sa["sink_value_sum"] == pytest.approx(sb["sink_value_sum"])
 
 
 def _gloo_worker(rank, world, port, q):

@@ -18,6 +18,10 @@ class _Pipeline:
     def step(self, tuples_per_source):
         self._p.step(int(tuples_per_source))
 
+    def steps(self, k, tuples_per_source):
+        """k steps streamed back to back; returns when the results of the last one reached the sinks."""
+        self._p.steps(int(k), int(tuples_per_source))
+
     def stats(self):
         return dict(self._p.stats())
 
