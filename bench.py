@@ -91,6 +91,16 @@ def rank_cpus(local_rank, world):
     GPU sits on the same node), or an equal contiguous slice of all allowed CPUs when the topology is unknown."""
     allowed = sorted(os.sched_getaffinity(0))
     nodes = [gpu_numa_node(i) for i in range(world)]
+    if not all(n is not None for n in nodes):
+        # sysfs does not tell (virtualised PCI topology): on the usual 8-GPU boards the GPUs are split evenly over the
+        # sockets in index order, so guess that when the host has several NUMA nodes with CPUs
+        try:
+            host_nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+            host_nodes = [n for n in host_nodes if open("/sys/devices/system/node/node%d/cpulist" % n).read().strip()]
+            if len(host_nodes) > 1 and world >= len(host_nodes):
+                nodes = [host_nodes[i * len(host_nodes) // world] for i in range(world)]
+        except OSError:
+            pass
     if all(n is not None for n in nodes):
         try:
             with open("/sys/devices/system/node/node%d/cpulist" % nodes[local_rank]) as f:
