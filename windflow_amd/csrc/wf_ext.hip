@@ -489,7 +489,10 @@ PYBIND11_MODULE(_C, m) {
     m.def("device_count", &gpu::device_count);
     m.def("device_pci_bus_id", [](int device) {
         char buf[64] = {0};
-        if (hipDeviceGetPCIBusId(buf, (int)sizeof(buf), device) != hipSuccess) return std::string();
+        if (hipDeviceGetPCIBusId(buf, (int)sizeof(buf), device) != hipSuccess) {
+            (void)hipGetLastError();  // a probe of a device that does not exist must not leave a sticky error behind
+            return std::string();
+        }
         return std::string(buf);
     }, py::arg("device"), "PCI address (domain:bus:device.function) of a GPU, without creating a context on it");
     m.def("tuple_size", []() { return sizeof(tuple_t); });

@@ -161,6 +161,7 @@ inline void preload_module(int device) {
     if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) return;  // reported where the device is first used
     if ((size_t)device >= done.size()) done.resize((size_t)device + 1, 0);
     if (done[(size_t)device]) return;
+    (void)hipGetLastError();  // errors of earlier, unrelated calls are not ours to report
     int prev = 0;
     WF_HIP_CHECK(hipGetDevice(&prev));
     WF_HIP_CHECK(hipSetDevice(device));
