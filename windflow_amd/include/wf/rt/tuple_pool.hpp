@@ -10,6 +10,10 @@
 //   live = OPEN_BIAS - frees                      while the owner still allocates from the block
 //   live = allocated - frees                      after the owner closed it (one fetch_sub of OPEN_BIAS - allocated)
 //   whoever brings it to 0 returns the block
+//
+// A block is recycled only when ALL its tuples are gone, so a long-lived tuple pins 64 KiB.  The runtime holds
+// tuples transiently (rings, ordering buffers, end-of-stream markers, all allocated back to back); operators that
+// keep data for long (window archives, per-key state) store copies by value, not pooled pointers.
 #pragma once
 #include <atomic>
 #include <cstddef>
