@@ -77,15 +77,18 @@ struct CombGPU {
     __host__ __device__ void operator()(const result_t& a, const result_t& b, result_t& out) const { out.value = a.value + b.value; }
 };
 
-// keys round-robin inside a per-source key range, progressive ids per key, stops after `seconds`
+// every source emits every key round-robin with progressive ids per key, and stops after `seconds`.  (Sources with
+// disjoint key sets would be a trap in DETERMINISTIC mode: the ordering nodes release a key's tuples up to the
+// smallest id seen on EVERY input channel, as in the reference, so a key that only one source produces is held
+// back until the end of the stream.)
 struct TimedSource {
     size_t n_keys, n_sources;
     uint64_t stop_at_us;
     std::atomic<uint64_t>* generated;
     uint64_t seq = 0;
-    bool operator()(tuple_t& t, RuntimeContext& ctx) {
+    bool operator()(tuple_t& t, RuntimeContext&) {
         const uint64_t s = seq++;
-        t.key = (s % n_keys) * n_sources + ctx.getReplicaIndex();
+        t.key = s % n_keys;
         t.id = s / n_keys;
         t.ts = t.id;
         t.value = (int64_t)(s & 1023);
@@ -125,7 +128,7 @@ int main(int argc, char** argv) {
         return 3;
     }
     std::atomic<uint64_t> generated{0}, results{0};
-    const size_t keys_per_source = std::max<size_t>(1, keys / sources);
+    const size_t keys_per_source = std::max<size_t>(1, keys);  // every source produces all the keys
     PipeGraph graph("bench_" + op, Mode::DETERMINISTIC);  // count-based windows need ordered input
     const uint64_t t0 = current_time_usecs();
     TimedSource gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), &generated};
@@ -147,7 +150,7 @@ int main(int argc, char** argv) {
         oper = KeyFFAT_Builder(lift_cpu, comb_cpu).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kff_gpu") {
         oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(64 * batch)
-                   .withMaxKeys(keys_per_source * sources + 64).withOutputCapacity(1 << 18).build_unique();
+                   .withMaxKeys(keys_per_source + 64).withOutputCapacity(1 << 18).build_unique();
     } else {
         std::cerr << "unknown operator " << op << std::endl;
         return 2;
@@ -159,7 +162,7 @@ int main(int argc, char** argv) {
     mp.add_sink(*sink);
     graph.run();
     const double elapsed = (current_time_usecs() - t0) / 1e6;
-    std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " win=" << win << " slide=" << slide
+    std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source << " win=" << win << " slide=" << slide
               << " batch=" << batch << " : " << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed
               << " windows/s), elapsed " << elapsed << " s" << std::endl;
     return 0;

@@ -239,6 +239,30 @@ inline bool edge_wait_on_host() {
     }();
     return h;
 }
+// HIP keeps host-side bookkeeping for the commands of a stream until the host SYNCHRONISES the stream: waiting on
+// events or querying is not enough (apps/bench/probe/hip_leak_probe.hip: ~1 KB per hipEventRecord, ~170 B per async
+// copy, linear and unbounded; zero with a hipStreamSynchronize now and then).  A lane only ever waits on events, so
+// its stream would accumulate ~3 KB of host memory per batch (24 MB/s on the flagship).  Every node therefore
+// synchronises its stream once per `stream_reap_interval()` batches (WF_STREAM_REAP, default 128; 0 = never): a
+// bubble of the few batches in flight, once in 128.
+inline uint32_t stream_reap_interval() {
+    static const uint32_t n = [] {
+        const char* e = std::getenv("WF_STREAM_REAP");
+        const long v = e ? std::atol(e) : 128;
+        return (uint32_t)(v < 0 ? 0 : v);
+    }();
+    return n;
+}
+struct StreamReaper {
+    uint32_t count = 0;
+    void tick(hipStream_t s) {
+        const uint32_t every = stream_reap_interval();
+        if (every != 0 && ++count >= every) {
+            count = 0;
+            WF_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+};
 // WF_D2H_STREAMS=shared: the device->host adapters of a device share one stream instead of owning one each
 inline bool d2h_shared_stream() {
     static const bool h = [] {

@@ -167,6 +167,7 @@ public:
         part_.partition(d, s, outs, kernels_);
         WF_HIP_CHECK(hipGetLastError());
         d->release(s);
+        reaper_.tick(s);
         for (size_t p = 0; p < n_dest_; p++) {
             outs[p]->ready.record(s);
             emit_to(outs[p], p);
@@ -183,6 +184,7 @@ private:
     size_t slabs_;
     gpu::BatchPartitioner<T> part_;
     std::unique_ptr<gpu::Stream> stream_;
+    gpu::StreamReaper reaper_;
     std::unique_ptr<gpu::BatchPool> in_pool_;
     uint64_t kernels_ = 0;
 };
