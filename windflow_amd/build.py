@@ -93,6 +93,7 @@ PROGRAMS = [
     ("apps/ysb/ysb_gpu.hip", "apps/bin/ysb_gpu", True),
     ("apps/bench/bench_ops_gpu.hip", "apps/bin/bench_ops_gpu", True),
     ("apps/bench/bench_win_gpu.hip", "apps/bin/bench_win_gpu", True),
+    ("apps/bench/probe/hip_leak_probe.hip", "apps/bin/hip_leak_probe", True),
     ("apps/bench/bench_cpu.cpp", "apps/bin/bench_cpu", False),
     ("examples/wordcount_windows.cpp", "apps/bin/example_wordcount", False),
     ("examples/gpu_pipeline.hip", "apps/bin/example_gpu_pipeline", True),
