@@ -30,7 +30,7 @@ BASELINES = {
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=25)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--drain-every-step", action="store_true",
                    help="wait for every step's results before feeding the next one (default: the K timed steps are streamed "
@@ -46,8 +46,8 @@ def parse_args():
     p.add_argument("--win", type=int, default=16, help="window length, in tuples of one key")
     p.add_argument("--slide", type=int, default=4, help="window slide, in tuples of one key")
     p.add_argument("--count-based", action="store_true", help="count-based instead of time-based windows")
-    p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(32 * 1024 * 1024))),
-                   help="tuples fed per GPU per step")
+    p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(256 * 1024 * 1024))),
+                   help="tuples fed per GPU per step (default 256 Mi: a step lasts ~0.2 s, so the driver's 20 steps time 4-5 s and ~40 000 batches)")
     p.add_argument("--inflight", type=int, default=0)
     p.add_argument("--agg-replicas", type=int, default=int(os.environ.get("WF_BENCH_AGG_REPLICAS", "0")),
                    help="keyby mode: Key_FFAT_GPU replicas behind the exchange (0: default)")

@@ -118,6 +118,34 @@ static void test_graph() {
     CHECK(eos == 3);  // one notification per input channel
 }
 
+// blocking mode: consumers sleep on their futex when the rings are empty, producers when a ring is full
+static void test_graph_blocking() {
+    rt::RuntimeConfig cfg;
+    cfg.queue_capacity = 4;
+    cfg.blocking = true;
+    rt::Graph g(cfg);
+    atomic<long> sum{0}, cnt{0};
+    atomic<int> eos{0};
+    const long N = 100000;
+    auto* p = g.adopt(new Producer(N));
+    auto* c = g.adopt(new Collector(&sum, &cnt, &eos));
+    rt::Node* adders[2];
+    for (int i = 0; i < 2; i++) {
+        auto* a = g.adopt(new Adder(1));
+        adders[i] = a;
+        g.connect_queue(p, p->add_out_port(), a);
+        g.connect_queue(a, a->add_out_port(), c);
+    }
+    g.run();
+    g.wait();
+    CHECK(cnt == N);
+    CHECK(sum == N * (N - 1) / 2 + N);
+    CHECK(eos == 2);
+    // with 4-slot rings somebody must have slept, and the time spent in svc() was measured
+    CHECK(p->counters().parks + c->counters().parks + adders[0]->counters().parks + adders[1]->counters().parks > 0);
+    CHECK(c->counters().busy_ns > 0);
+}
+
 // ---- tuples with string keys -----------------------------------------------------------------------
 struct skey_t {
     string key;
@@ -267,6 +295,9 @@ static void test_stats_and_dot() {
     CHECK(in_filter == 9000);
     CHECK(out_filter == 3000);
     CHECK(in_map == 3000);
+    // the filter replicas are thread heads: their service time is measured; the chained map shares their threads
+    for (auto& r : f.get_StatsRecords()) CHECK(r.service_time_measured && r.service_time_us > 0.0 && r.busy_time_us <= r.end_time_us - r.start_time_us);
+    for (auto& r : m.get_StatsRecords()) CHECK(!r.service_time_measured);
 }
 
 // ---- late tuples are dropped and accounted (DEFAULT mode, time-based windows) -----------------------------------
@@ -431,6 +462,7 @@ int main(int argc, char** argv) {
     if (argc == 3 && strcmp(argv[1], "illegal") == 0) return illegal(atoi(argv[2]));
     test_spsc();
     test_graph();
+    test_graph_blocking();
     test_string_keys();
     test_flatfat();
     test_stats_and_dot();

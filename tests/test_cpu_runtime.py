@@ -63,6 +63,25 @@ def test_mp_windows_tumbling_and_dense_sliding(win, slide):
         assert out.count("  OK") == 2 and "FAILED" not in out
 
 
+@pytest.mark.parametrize("op", ["seq", "kf", "wf", "wmr", "kf+wmr", "wf+wmr"])
+@pytest.mark.parametrize("mode", ["cb", "tb"])
+def test_mp_windows_hopping(op, mode):
+    """Hopping windows (win < slide, reference win_seq.hpp:352-365): tuples in the gaps belong to no window but still
+    close the window before them, so every operator emits the same windows as the sequential oracle."""
+    win, slide = ("3", "10") if mode == "cb" else ("300", "1000")
+    out = run_cpp("test_mp_windows", ["-t", op, "-m", mode, "-r", 2, "-l", 1500, "-k", 5, "-w", win, "-s", slide])
+    assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+@pytest.mark.parametrize("op,mode", [("kf", "tb"), ("wf", "cb"), ("pf", "tb")])
+def test_mp_windows_blocking_mode(op, mode):
+    """WF_BLOCKING=1: idle threads sleep on a futex and are woken by the producer (rt/spsc_queue.hpp Parker)."""
+    win, slide = ("14", "4") if mode == "cb" else ("1000", "300")
+    out = run_cpp("test_mp_windows", ["-t", op, "-m", mode, "-r", 2, "-l", 1500, "-k", 5, "-w", win, "-s", slide],
+                  env={"WF_BLOCKING": "1", "WF_QUEUE_CAPACITY": "64"})
+    assert out.count("  OK") == 2 and "FAILED" not in out
+
+
 GRAPH_SCENARIOS = ["merge_1", "merge_2", "merge_3", "merge_4", "split_1", "split_2", "split_3", "split_4", "split_5",
                    "graph_1", "graph_2", "graph_3", "graph_4", "graph_5", "graph_6", "graph_7", "graph_8", "graph_9"]
 

@@ -167,6 +167,7 @@ private:
                     f.dev->count_on_host = true;
                 }
                 gpu::TraceRange tr("wf:drain_batch");
+                if (f.dev->host_hdr.count > pool_->capacity()) gpu::failwith("DeviceToHost: a batch larger than the first one received");
                 gpu::Batch* h = pool_->acquire_host();
                 h->host_hdr = f.dev->host_hdr;
                 const size_t bytes = (size_t)h->host_hdr.count * sizeof(T);
@@ -502,6 +503,7 @@ public:
         }
         while (!uploading_.empty()) pump_uploads(true);
         gpu_flush();
+        foreign_.drain();
     }
 
     // uploads complete while the input queue is empty: hand them to the kernels without waiting for the next batch
@@ -527,6 +529,8 @@ protected:
         s.bytes_copied_dh = bytes_dh_;
     }
     hipStream_t stream() const { return stream_->get(); }
+    // hand an input slab back after the work enqueued so far (whichever GPU's context owns the slab)
+    void release_input(gpu::Batch* b) { gpu::release_after(b, stream(), cfg_.gpu_id, foreign_); }
     // record completion on the batch and pass it downstream
     void emit_device(gpu::Batch* d) {
         d->ready.record(stream());
@@ -554,15 +558,18 @@ private:
         }
         if (!dev_in_pool_)
             dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), d->capacity, cfg_.pool_slabs));
+        if (d->capacity > dev_in_pool_->capacity()) gpu::failwith("GPU operator: a batch larger than the first one received (producers with different batch lengths?)");
         gpu::Batch* mine = dev_in_pool_->acquire(stream());
-        d->ready.wait_on(stream());
+        // the producer's event belongs to the other GPU: the copy must not start before it, and a cross-device
+        // hipStreamWaitEvent is legal, but the wait happens on the host like every other inter-stream wait here
+        d->ready.host_sync();
         mine->host_hdr = d->host_hdr;
         mine->count_on_host = true;
         WF_HIP_CHECK(hipMemcpyAsync(mine->slab, &mine->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, stream()));
         const size_t bytes = (size_t)d->host_hdr.count * sizeof(in_t);
         if (bytes > 0)
             WF_HIP_CHECK(hipMemcpyPeerAsync(mine->template data<in_t>(), cfg_.gpu_id, d->template data<in_t>(), d->device, bytes, stream()));
-        d->release(stream());
+        foreign_.release(d, stream());  // d's own event cannot be recorded on a stream of this GPU
         mine->ready.record(stream());
         return mine;
     }
@@ -576,6 +583,7 @@ private:
                                  ? stream()
                                  : gpu::shared_copy_stream(cfg_.gpu_id, 1 + (int)(this->context.getReplicaIndex() % gpu::upload_streams()));
         }
+        if (h->capacity > dev_in_pool_->capacity()) gpu::failwith("GPU operator: a batch larger than the first one received (producers with different batch lengths?)");
         gpu::Batch* d = dev_in_pool_->acquire(upload_stream_);
         *h->header() = h->host_hdr;  // the header travels in the slab
         const size_t bytes = h->bytes_used();
@@ -583,7 +591,7 @@ private:
         bytes_hd_ += bytes;
         d->host_hdr = h->host_hdr;
         d->count_on_host = true;
-        h->release(upload_stream_);
+        gpu::release_after(h, upload_stream_, cfg_.gpu_id, foreign_);  // the pinned slab may belong to another GPU's context
         reaper_.tick(stream());
         if (upload_stream_ == stream()) {  // uploads in the compute stream: stream order is all the kernels need
             process_device(d);
@@ -612,6 +620,7 @@ private:
     }
 
     hipStream_t upload_stream_ = nullptr;
+    gpu::ForeignReleaser foreign_;
     std::deque<gpu::Batch*> uploading_;
     gpu::StreamReaper reaper_;
     std::unique_ptr<gpu::Stream> stream_;

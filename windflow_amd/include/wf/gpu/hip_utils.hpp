@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -470,6 +471,50 @@ inline void Batch::release(hipStream_t last_use_stream) {
     pool->put(this);
 }
 inline void Batch::release_host() { pool->put(this); }
+
+// A slab's `ready` event belongs to the device that was current when its pool created it; HIP refuses to record an
+// event on a stream of another device (hipErrorInvalidHandle).  A consumer on GPU B that has enqueued its last use of
+// a slab owned by GPU A (a peer copy, an upload from a pinned slab allocated under A's context) therefore cannot call
+// Batch::release(stream of B).  It parks the slab here instead: an event of its OWN device is recorded behind the
+// last use, and the slab goes back to its pool (whose next user then has nothing to wait for) once that event has
+// completed - polled whenever the consumer releases the next slab, waited for when too many are parked.
+class ForeignReleaser {
+public:
+    explicit ForeignReleaser(size_t max_parked = 2) : max_parked_(max_parked) {}
+    ~ForeignReleaser() { drain(); }
+    // `s` must be a stream of the calling thread's current device
+    void release(Batch* b, hipStream_t s) {
+        std::unique_ptr<Event> e(new Event());
+        e->record(s);
+        parked_.emplace_back(std::move(e), b);
+        poll();
+        while (parked_.size() > max_parked_) pop_front(true);
+    }
+    void poll() {
+        while (!parked_.empty() && parked_.front().first->done()) pop_front(false);
+    }
+    void drain() {
+        while (!parked_.empty()) pop_front(true);
+    }
+    size_t parked() const { return parked_.size(); }
+
+private:
+    void pop_front(bool wait) {
+        if (wait) parked_.front().first->host_sync();
+        parked_.front().second->release_host();
+        parked_.pop_front();
+    }
+    size_t max_parked_;
+    std::deque<std::pair<std::unique_ptr<Event>, Batch*>> parked_;
+};
+
+// release `b` after the work enqueued on `s` (a stream of device `stream_device`, current in the calling thread)
+inline void release_after(Batch* b, hipStream_t s, int stream_device, ForeignReleaser& foreign) {
+    if (b->device == stream_device)
+        b->release(s);
+    else
+        foreign.release(b, s);
+}
 
 }  // namespace gpu
 }  // namespace wf

@@ -936,7 +936,22 @@ protected:
         gpu::Batch* out = engine_->process(d, this->stream(), this->num_kernels_);
         d->release(this->stream());
         this->emit_device(out);
+        // an unbounded stream never reaches gpu_flush(): lost results / unassigned keys are also looked for periodically
+        if (++since_check_ >= 256) {
+            since_check_ = 0;
+            check_counters(engine_->read_counters(this->stream()));
+        }
     }
+    void check_counters(const gpu::FFATCounters& c) {
+        // losing results silently is not an option: fail loudly and say which knob to turn
+        if (c.overflow > 0)
+            fatal_error("Key_FFAT_GPU: " + std::to_string(c.overflow) + " window results did not fit the output batches; raise the output capacity "
+                        "(KeyFFATGPU_Builder::withOutputCapacity)");
+        if (c.table_full > 0)
+            fatal_error("Key_FFAT_GPU: tuples without a state slot - the device key table is full (raise KeyFFATGPU_Builder::withMaxKeys) or a "
+                        "tuple carries the reserved key 2^64-1");
+    }
+    uint32_t since_check_ = 0;
     void gpu_flush() override {
         if (!engine_) return;
         size_t cursor = 0;
@@ -945,12 +960,7 @@ protected:
         const gpu::FFATCounters c = engine_->read_counters(this->stream());
         if (counters_) (*counters_)[this->context.getReplicaIndex()] = c;
         dropped_ = c.dropped;
-        // losing results silently is not an option: fail loudly and say which knob to turn
-        if (c.overflow > 0)
-            fatal_error("Key_FFAT_GPU: " + std::to_string(c.overflow) + " window results did not fit the output batches; raise the output capacity "
-                        "(KeyFFATGPU_Builder::withOutputCapacity)");
-        if (c.table_full > 0)
-            fatal_error("Key_FFAT_GPU: the device key table is full; raise KeyFFATGPU_Builder::withMaxKeys");
+        check_counters(c);
     }
 
     void finalize_stats(Stats_Record& s) override {

@@ -78,6 +78,7 @@ public:
     // enqueue on `s`; `outs` receives n_dest batches whose counts live on the device (+ pinned mirrors)
     void partition(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels) {
         const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
+        if (pool_ && upper > pool_->capacity()) failwith("BatchPartitioner: a batch larger than the first one received");
         if (!pool_) {
             pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(T), in->capacity, n_dest_ * pool_slabs_));
             dest_.resize(in->capacity);
@@ -149,13 +150,15 @@ public:
         hipStream_t s = stream_->get();
         if (in_kind_ == EDGE_HOST_BATCH) {
             if (!in_pool_) in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, device_, sizeof(T), b->capacity, slabs_));
+            if (b->capacity > in_pool_->capacity()) gpu::failwith("KeyBy_EmitterGPU: a batch larger than the first one received");
             d = in_pool_->acquire(s);
             *b->header() = b->host_hdr;
             WF_HIP_CHECK(hipMemcpyAsync(d->slab, b->slab, b->bytes_used(), hipMemcpyHostToDevice, s));
             d->host_hdr = b->host_hdr;
             d->count_on_host = true;
-            b->release(s);
+            gpu::release_after(b, s, device_, foreign_);  // the pinned slab may belong to another GPU's context
         } else {
+            if (d->device != device_) gpu::failwith("KeyBy_EmitterGPU: device batch produced on another GPU; place the producer and the keyed operator on the same GPU");
             d->ready.edge_wait(s);
         }
         if (n_dest_ == 1) {
@@ -173,11 +176,13 @@ public:
             emit_to(outs[p], p);
         }
     }
+    void flush() override { foreign_.drain(); }
     void svc_end() override {
         if (stream_) stream_->sync();
     }
 
 private:
+    gpu::ForeignReleaser foreign_;
     size_t n_dest_;
     edge_kind_t in_kind_;
     int device_;

@@ -38,7 +38,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t slot = sslot[i];
         if (i > 0 && sslot[i - 1] == slot) continue;
         if (slot == 0xffffffffu) {
-            atomicAdd(table_full, 1u);
+            // tuples without a slot (table full / reserved key) are not processed: the operator fails at its next check;
+            // until then their outputs are defined (zeroed results, tuples dropped by a filter) rather than garbage
+            uint32_t cnt = 0;
+            for (uint32_t j = i; j < n && sslot[j] == slot; j++, cnt++) {
+                if constexpr (MODE == 1) out[sidx[j]] = R{};
+                if constexpr (MODE == 2) flags[sidx[j]] = 0;
+            }
+            atomicAdd(table_full, cnt);
             continue;
         }
         if (i + KEYED_LONG_RUN - 1 < n && sslot[i + KEYED_LONG_RUN - 1] == slot) {  // left to the wave-per-run kernel
@@ -258,10 +265,18 @@ public:
 protected:
     void process_device(gpu::Batch* d) override {
         hipStream_t s = this->stream();
-        if (!ctx_) ctx_.reset(new gpu::KeyedContext(kcfg_.max_keys, kcfg_.state_size, d->capacity, this->cfg_.gpu_id));
+        if (!ctx_) {
+            ctx_.reset(new gpu::KeyedContext(kcfg_.max_keys, kcfg_.state_size, d->capacity, this->cfg_.gpu_id));
+            batch_cap_ = d->capacity;
+        }
+        if (d->capacity > batch_cap_) gpu::failwith("keyed GPU operator: a batch larger than the first one received");
         const size_t upper = std::max<size_t>(1, d->count_on_host ? d->host_hdr.count : d->capacity);
         const auto sorted = ctx_->template group<tuple_t>(d, s, this->num_kernels_);
         const unsigned grid = gpu::grid_for(upper);
+        if (++since_check_ >= CHECK_EVERY) {
+            since_check_ = 0;
+            check_table();
+        }
         if constexpr (MODE == 0) {
             launch_apply<tuple_t>(d, (tuple_t*)nullptr, (uint8_t*)nullptr, sorted, upper, grid, s);
             this->emit_device(d);
@@ -296,10 +311,15 @@ protected:
             this->emit_device(o);
         }
     }
-    void gpu_flush() override {
+    void gpu_flush() override { check_table(); }
+    // an unbounded stream never reaches gpu_flush(): the counter is also read every CHECK_EVERY batches
+    void check_table() {
         if (ctx_ && ctx_->read_table_full(this->stream()) > 0)
-            fatal_error("keyed GPU operator: the device key table is full; raise withMaxKeys()");
+            fatal_error("keyed GPU operator: tuples without a state slot - the device key table is full (raise withMaxKeys()) or a tuple "
+                        "carries the reserved key 2^64-1");
     }
+    static constexpr uint32_t CHECK_EVERY = 256;
+    uint32_t since_check_ = 0;
 
 private:
     // short runs: a thread per run; long runs: a wave per run (recorded by the first kernel)
@@ -321,6 +341,7 @@ private:
 
     F func_;
     KeyedGPUConfig kcfg_;
+    size_t batch_cap_ = 0;
     std::unique_ptr<gpu::KeyedContext> ctx_;
     std::unique_ptr<gpu::BatchPool> out_pool_;
     gpu::DeviceBuffer<uint8_t> flags_;

@@ -137,8 +137,11 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-// returns the slot (table position) of `key`, inserting it if absent; 0xffffffff if full
+// returns the slot (table position) of `key`, inserting it if absent; 0xffffffff if the table is full or the key is
+// the reserved value 2^64-1 (the empty-slot sentinel: accepting it would let two keys share a slot).  Callers count
+// such tuples and the operators fail loudly on them.
 __device__ __forceinline__ uint32_t key_table_slot(unsigned long long* table, uint32_t mask, unsigned long long key) {
+    if (key == KEY_EMPTY) return 0xffffffffu;
     uint32_t h = (uint32_t)mix64(key) & mask;
     for (uint32_t probes = 0; probes <= mask; probes++) {
         unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -531,26 +534,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         dest[i] = (uint32_t)(((mix64((uint64_t)keyfn(data[i])) >> hash_shift) & 0xffffffull) % n_dest);
         idx[i] = i;
     }
-}
-
-// gather tuples through a permutation; also derives the per-destination offsets
-// from the sorted destination array (offsets[d] = first position with dest >= d)
-template <typename T>
-__global__ void __launch_bounds__(BLOCK_THREADS)
-    gather_partition_kernel(const BatchHeader* hdr, const T* in, const uint32_t* sorted_dest, const uint32_t* perm, T* out, uint32_t n_dest,
-                            uint32_t* offsets /*[n_dest+1]*/) {
-    const uint32_t n = hdr->count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        out[i] = in[perm[i]];
-        const uint32_t d = sorted_dest[i];
-        const uint32_t prev = (i == 0) ? 0u : sorted_dest[i - 1] + 1u;
-        // every destination in (prev_dest, d] starts here
-        for (uint32_t x = (i == 0 ? 0u : prev); x <= d; x++) offsets[x] = i;
-        if (i == n - 1)
-            for (uint32_t x = d + 1; x <= n_dest; x++) offsets[x] = n;
-    }
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0)
-        for (uint32_t x = 0; x <= n_dest; x++) offsets[x] = 0;
 }
 
 }  // namespace gpu

@@ -4,7 +4,10 @@
 // ff_a2a composition + run/wait of the reference's substrate.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <memory>
 #include <set>
 #include <stdexcept>
@@ -81,6 +84,9 @@ public:
             groups.push_back(std::move(g));
         }
         running_ = true;
+        parkers_.clear();
+        for (size_t i = 0; i < hs.size(); i++) parkers_.emplace_back(new Parker());
+        pin_list_ = cfg_.pin_threads ? cpu_list() : std::vector<int>();
         threads_.reserve(hs.size());
         for (size_t i = 0; i < hs.size(); i++) {
             threads_.emplace_back([this, i, h = hs[i], g = groups[i]]() { thread_main(i, h, g); });
@@ -113,18 +119,54 @@ private:
             if (o.fused != nullptr) collect(o.fused, g, seen);
     }
 
-    void thread_main(size_t idx, Node* head, const std::vector<Node*>& group) {
-        if (cfg_.pin_threads) {
-            unsigned nc = std::max(1u, std::thread::hardware_concurrency());
+    // CPUs the threads are pinned to, round-robin: WF_PIN_CPUS ("0-15,32-47") or, by default, the CPUs the process
+    // is allowed to run on - a launcher that binds each rank to the NUMA node of its GPU (bench.py does) thereby
+    // keeps every runtime thread, and the pinned slabs it first touches, on that node
+    std::vector<int> cpu_list() const {
+        std::vector<int> cpus;
+        const std::string& spec = cfg_.pin_cpus;
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t end = spec.find(',', pos);
+            if (end == std::string::npos) end = spec.size();
+            const std::string part = spec.substr(pos, end - pos);
+            pos = end + 1;
+            if (part.empty()) continue;
+            const size_t dash = part.find('-');
+            const int lo = std::atoi(part.substr(0, dash).c_str());
+            const int hi = dash == std::string::npos ? lo : std::atoi(part.substr(dash + 1).c_str());
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) cpus.push_back(c);
+        }
+        if (cpus.empty()) {
             cpu_set_t set;
             CPU_ZERO(&set);
-            CPU_SET(idx % nc, &set);
+            if (sched_getaffinity(0, sizeof(set), &set) == 0)
+                for (int c = 0; c < CPU_SETSIZE; c++)
+                    if (CPU_ISSET(c, &set)) cpus.push_back(c);
+        }
+        if (cpus.empty()) cpus.push_back(0);
+        return cpus;
+    }
+
+    static uint64_t now_ns() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+
+    void thread_main(size_t idx, Node* head, const std::vector<Node*>& group) {
+        if (!pin_list_.empty()) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(pin_list_[idx % pin_list_.size()], &set);
             pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
         }
+        Parker* parker = parkers_[idx].get();
+        this_thread_parker() = parker;
         for (Node* n : group) n->svc_init();
         if (head->is_source()) {
+            const uint64_t t0 = now_ns();
             while (head->generate()) {
             }
+            head->counters_.busy_ns += now_ns() - t0;  // a source is always busy (time blocked on a full ring included)
             head->terminate();
         } else {
             constexpr size_t BULK = 64;
@@ -135,6 +177,10 @@ private:
             std::vector<Node*> idlers;
             for (Node* n : group)
                 if (n->wants_idle()) idlers.push_back(n);
+            const bool blocking = cfg_.blocking;
+            if (blocking)
+                for (SPSCQueue* q : head->in_) q->consumer_parker.store(parker, std::memory_order_relaxed);
+            unsigned idle_rounds = 0;
             while (!active.empty()) {
                 bool progress = false;
                 for (size_t a = 0; a < active.size();) {
@@ -142,13 +188,20 @@ private:
                     SPSCQueue* q = head->in_[ch];
                     const size_t n = q->pop_bulk(buf, BULK);
                     bool ended = false;
-                    for (size_t i = 0; i < n; i++) {
-                        if (buf[i] == eos_token()) {
-                            ended = true;  // producer never pushes after EOS
-                            break;
+                    if (n > 0) {
+                        if (blocking) q->wake_producer();
+                        // service time is measured per bulk (two clock reads per up to 64 messages), successors fused in
+                        // this thread included
+                        const uint64_t t0 = now_ns();
+                        for (size_t i = 0; i < n; i++) {
+                            if (buf[i] == eos_token()) {
+                                ended = true;  // producer never pushes after EOS
+                                break;
+                            }
+                            head->counters_.inputs++;
+                            head->svc(buf[i], ch);
                         }
-                        head->counters_.inputs++;
-                        head->svc(buf[i], ch);
+                        head->counters_.busy_ns += now_ns() - t0;
                     }
                     if (n > 0) progress = true;
                     if (ended) {
@@ -161,9 +214,26 @@ private:
                 }
                 if (progress) {
                     backoff.reset();
+                    idle_rounds = 0;
                 } else {
                     for (Node* n : idlers) n->on_idle();
-                    backoff.pause();
+                    if (!blocking) {
+                        backoff.pause();
+                    } else if (++idle_rounds < 4) {
+                        sched_yield();
+                    } else {
+                        // sleep on the futex until a producer pushes into one of the input rings (nodes with work in
+                        // flight on the device are polled every idle_poll_us instead)
+                        parker->announce();
+                        bool any = false;
+                        for (int ch : active) any = any || !head->in_[ch]->empty_approx();
+                        if (any) {
+                            parker->cancel();
+                        } else {
+                            parker->park(idlers.empty() ? cfg_.park_timeout_us : std::min(cfg_.park_timeout_us, 100u));
+                            head->counters_.parks++;
+                        }
+                    }
                 }
             }
             if (head->in_.empty()) head->terminate();
@@ -175,6 +245,8 @@ private:
     std::vector<std::unique_ptr<Node>> nodes_;
     std::vector<std::unique_ptr<SPSCQueue>> queues_;
     std::vector<std::thread> threads_;
+    std::vector<std::unique_ptr<Parker>> parkers_;
+    std::vector<int> pin_list_;
     bool running_ = false;
     bool done_ = false;
 };

@@ -43,6 +43,12 @@ inline void cpu_relax() {
 #endif
 }
 
+// the Parker of the calling runtime thread (set by Graph::thread_main; nullptr outside the runtime)
+inline Parker*& this_thread_parker() {
+    static thread_local Parker* p = nullptr;
+    return p;
+}
+
 // spin -> yield -> sleep back-off helper
 class Backoff {
 public:
@@ -69,7 +75,8 @@ private:
 struct NodeCounters {
     uint64_t inputs = 0;
     uint64_t outputs = 0;
-    uint64_t busy_ns = 0;  // filled by the thread loop (sampled)
+    uint64_t busy_ns = 0;  // head nodes: time spent inside svc()/generate(), fused successors included (thread loop)
+    uint64_t parks = 0;    // head nodes, blocking mode: times the thread went to sleep on its futex
 };
 
 class Graph;
@@ -116,6 +123,7 @@ public:
             o.fused->svc(m, o.fused_ch);
         } else if (o.q != nullptr) {
             if (!o.q->try_push(m)) push_slow(o.q, m);
+            if (cfg_->blocking) o.q->wake_consumer();
         }
         // unconnected port: message is dropped by design (caller keeps ownership rules)
     }
@@ -149,8 +157,10 @@ public:
         for (Port& o : out_) {
             if (o.fused != nullptr)
                 o.fused->input_ended(o.fused_ch);
-            else if (o.q != nullptr)
+            else if (o.q != nullptr) {
                 push_slow(o.q, eos_token());
+                if (cfg_->blocking) o.q->wake_consumer();
+            }
         }
     }
 
@@ -163,6 +173,20 @@ private:
     };
 
     void push_slow(SPSCQueue* q, void* m) {
+        Parker* me = cfg_->blocking ? this_thread_parker() : nullptr;
+        if (me != nullptr) {
+            // blocking mode: sleep until the consumer pops (it wakes the producer it finds registered on the ring)
+            q->producer_parker.store(me, std::memory_order_relaxed);
+            while (true) {
+                me->announce();
+                if (q->try_push(m)) {
+                    me->cancel();
+                    return;
+                }
+                me->park(cfg_->park_timeout_us);
+                counters_.parks++;
+            }
+        }
         Backoff b(cfg_);
         while (!q->try_push(m)) b.pause();
     }

@@ -42,7 +42,16 @@ public:
         stats_.bytes_received = counters().inputs * in_bytes_;
         stats_.bytes_sent = counters().outputs * out_bytes_;
         const double run_us = (double)(stats_.end_time_us - stats_.start_time_us);
-        if (stats_.inputs_received > 0) stats_.service_time_us = run_us / (double)stats_.inputs_received;
+        // per-input service time as the thread loop measured it (reference: wf/win_seq.hpp:306-313, :453-463 measure every
+        // svc() call; here one pair of clock reads covers a bulk of up to 64 messages).  A replica fused behind another node
+        // has no measurement of its own: its time is part of the head's.
+        stats_.busy_time_us = counters().busy_ns / 1000;
+        stats_.parks = counters().parks;
+        stats_.service_time_measured = counters().busy_ns > 0;
+        if (stats_.service_time_measured) {
+            const uint64_t units = stats_.inputs_received > 0 ? stats_.inputs_received : stats_.outputs_sent;  // sources: per output
+            if (units > 0) stats_.service_time_us = (double)counters().busy_ns / 1000.0 / (double)units;
+        }
         if (stats_.outputs_sent > 0) stats_.eff_service_time_us = run_us / (double)stats_.outputs_sent;
         finalize_stats(stats_);
         if (hub_) hub_->add(stats_);

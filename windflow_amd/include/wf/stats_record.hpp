@@ -25,8 +25,11 @@ struct Stats_Record {
     uint64_t bytes_received = 0;
     uint64_t outputs_sent = 0;
     uint64_t bytes_sent = 0;
-    double service_time_us = 0.0;      // average per-input service time
-    double eff_service_time_us = 0.0;  // average inter-departure time
+    double service_time_us = 0.0;      // average per-input service time: time inside svc() (fused successors included) / inputs
+    double eff_service_time_us = 0.0;  // average inter-departure time: running time / outputs
+    bool service_time_measured = false;  // false: the replica runs fused in another node's thread, whose record holds the time
+    uint64_t busy_time_us = 0;         // time the replica's thread spent processing (not waiting for input)
+    uint64_t parks = 0;                // blocking mode: times the thread slept waiting for input
     // GPU replicas
     uint64_t num_kernels = 0;
     uint64_t bytes_copied_hd = 0;
@@ -42,7 +45,8 @@ struct Stats_Record {
           << ",\"window\":" << (isWinOperator ? "true" : "false") << ",\"inputs_received\":" << inputs_received
           << ",\"inputs_ignored\":" << inputs_ignored << ",\"bytes_received\":" << bytes_received << ",\"outputs_sent\":" << outputs_sent
           << ",\"bytes_sent\":" << bytes_sent << ",\"service_time_us\":" << service_time_us
-          << ",\"eff_service_time_us\":" << eff_service_time_us << ",\"running_time_us\":" << (end_time_us - start_time_us);
+          << ",\"service_time_measured\":" << (service_time_measured ? "true" : "false") << ",\"eff_service_time_us\":" << eff_service_time_us
+          << ",\"busy_time_us\":" << busy_time_us << ",\"parks\":" << parks << ",\"running_time_us\":" << (end_time_us - start_time_us);
         if (isGPUReplica)
             o << ",\"num_kernels\":" << num_kernels << ",\"bytes_copied_hd\":" << bytes_copied_hd << ",\"bytes_copied_dh\":" << bytes_copied_dh;
         o << "}";

@@ -85,18 +85,20 @@ public:
         // last window containing (or preceding) the tuple
         long last_w;
         const uint64_t rel = ord - wa.initial_id;
+        bool in_gap = false;
         if (p_.win_len >= p_.slide_len) {
             last_w = (long)((rel + 1 + p_.slide_len - 1) / p_.slide_len) - 1;  // ceil((rel+1)/slide) - 1
         } else {
+            // hopping windows: a tuple that falls in the gap after window n belongs to no window, but - like an
+            // end-of-stream marker - it still proves that window n is over: the windows up to n are opened and fired
+            // before it is discarded.  (The reference discards it first, win_seq.hpp:352-365, so its Key_Farm emits
+            // fewer trailing empty windows than its Win_Farm on the same stream; here every operator agrees.)
             const uint64_t n = rel / p_.slide_len;
             last_w = (long)n;
-            if (rel >= n * p_.slide_len + p_.win_len && !marker) {  // falls in a gap between hopping windows
-                tuple_delete(t);
-                return;
-            }
+            in_gap = rel >= n * p_.slide_len + p_.win_len;
         }
         if constexpr (isNIC) {
-            if (!marker) kd.archive.insert(*t);
+            if (!marker && !in_gap) kd.archive.insert(*t);
         }
         // open the windows this tuple reaches
         for (long lwid = (long)kd.next_lwid; lwid <= last_w; lwid++) {
@@ -111,7 +113,7 @@ public:
             kd.wins.pop_front();
         }
         // windows containing the tuple are the contiguous range [first_w, last_w]
-        if (!marker && !kd.wins.empty()) {
+        if (!marker && !in_gap && !kd.wins.empty()) {
             uint64_t first_w;
             if (p_.win_len >= p_.slide_len)
                 first_w = (rel + 1 < p_.win_len) ? 0 : (rel + 1 - p_.win_len + p_.slide_len - 1) / p_.slide_len;

@@ -55,10 +55,9 @@ struct Window {
     }
     win_event_t onOrdinal(uint64_t ord, win_type_t type, uint64_t delay) const {
         if (batched) return BATCHED;
-        if (ord < start) return OLD;
-        if (ord < end) return IN;
-        if (type == TB && ord < end + delay) return DELAYED;
-        return FIRED;
+        // the window carries its own bounds: a triggerer anchored at `start` with lwid 0
+        if (type == CB) return Triggerer_CB(end - start, 0, 0, start)(ord);
+        return Triggerer_TB(end - start, 0, 0, start, delay)(ord);
     }
 };
 
