@@ -56,6 +56,14 @@ static B& set_windows(B& b, const Cfg& c) {
         b.withTBWindows(us(c.win), us(c.slide), c.mode == "tbd" ? us(50000000) : us(0));
     return b;
 }
+// non-incremental engines keep the tuples of open windows on the device: with a 50 s triggering delay that is the whole stream
+template <typename B>
+static B& set_nic_windows(B& b, const Cfg& c) {
+    set_windows(b, c);
+    b.withMaxKeys(64);
+    if (c.mode == "tbd") b.withArchiveCapacity(3 * c.len);
+    return b;
+}
 
 static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector<shared_ptr<Basic_Operator>>& keep, string& descr) {
     std::uniform_int_distribution<int> d(1, 4);
@@ -69,25 +77,31 @@ static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector
     descr = c.op + " batch=" + to_string(batch) + " par=(" + to_string(p1) + "," + to_string(p2) + "," + to_string(p3) + ")";
     if (c.op == "seq") {
         auto b = WinSeqGPU_Builder(Win_GPU());
-        mp.add(*hold(set_windows(b, c).withName("seq_gpu").withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("seq_gpu").withBatch(batch).build_ptr()));
     } else if (c.op == "kf") {
         auto b = KeyFarmGPU_Builder(Win_GPU());
-        mp.add(*hold(set_windows(b, c).withName("kf_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("kf_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
     } else if (c.op == "wf") {
         auto b = WinFarmGPU_Builder(Win_GPU());
-        mp.add(*hold(set_windows(b, c).withName("wf_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("wf_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
     } else if (c.op == "pf_plq") {
         auto b = PaneFarmGPU_Builder(Win_GPU(), win2_nic);
-        mp.add(*hold(set_windows(b, c).withName("pf_gpu").withParallelism(p1, p2).withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("pf_gpu").withParallelism(p1, p2).withBatch(batch).build_ptr()));
     } else if (c.op == "pf_wlq") {
         auto b = PaneFarmGPU_Builder(win_nic, Win2_GPU());
-        mp.add(*hold(set_windows(b, c).withName("pf_gpu").withParallelism(p1, p2).withBatch(batch).withScratchpad(16).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("pf_gpu").withParallelism(p1, p2).withBatch(batch).withScratchpad(16).build_ptr()));
     } else if (c.op == "wmr_map") {
         auto b = WinMapReduceGPU_Builder(Win_GPU(), win2_inc);
-        mp.add(*hold(set_windows(b, c).withName("wmr_gpu").withParallelism(p1 + 1, p2).withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("wmr_gpu").withParallelism(p1 + 1, p2).withBatch(batch).build_ptr()));
     } else if (c.op == "wmr_red") {
         auto b = WinMapReduceGPU_Builder(win_inc, Win2_GPU());
-        mp.add(*hold(set_windows(b, c).withName("wmr_gpu").withParallelism(p1 + 1, p2).withBatch(batch).build_ptr()));
+        mp.add(*hold(set_nic_windows(b, c).withName("wmr_gpu").withParallelism(p1 + 1, p2).withBatch(batch).build_ptr()));
+    } else if (c.op == "kf_wr") {  // associative form: a wave64 per window
+        auto b = KeyFarmGPU_Builder(gpu::wave_reduce(Lift_GPU(), Comb_GPU()));
+        mp.add(*hold(set_nic_windows(b, c).withName("kf_wr_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
+    } else if (c.op == "wf_wr") {
+        auto b = WinFarmGPU_Builder(gpu::wave_reduce(Lift_GPU(), Comb_GPU()));
+        mp.add(*hold(set_nic_windows(b, c).withName("wf_wr_gpu").withParallelism(p1).withBatch(batch).build_ptr()));
     } else if (c.op == "kff") {
         auto b = KeyFFATGPU_Builder(Lift_GPU(), Comb_GPU());
         mp.add(*hold(set_windows(b, c).withName("kff_gpu").withParallelism(p1).withBatch(64 * batch).withMaxKeys(64).withOutputCapacity(1 << 17).build_ptr()));
@@ -97,11 +111,11 @@ static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector
                          .build_ptr()));
     } else if (c.op == "kf+pf") {
         auto b = PaneFarmGPU_Builder(Win_GPU(), win2_nic);
-        auto* pf = hold(set_windows(b, c).withName("pf_inner").withParallelism(p2, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        auto* pf = hold(set_nic_windows(b, c).withName("pf_inner").withParallelism(p2, p3).withBatch(batch).prepare4Nesting().build_ptr());
         mp.add(*hold(KeyFarmGPU_Builder(*pf).withName("kf_pf_gpu").withParallelism(p1).build_ptr()));
     } else if (c.op == "wf+wmr") {
         auto b = WinMapReduceGPU_Builder(win_nic, Win2_GPU());
-        auto* wmr = hold(set_windows(b, c).withName("wmr_inner").withParallelism(p2 + 1, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        auto* wmr = hold(set_nic_windows(b, c).withName("wmr_inner").withParallelism(p2 + 1, p3).withBatch(batch).prepare4Nesting().build_ptr());
         mp.add(*hold(WinFarmGPU_Builder(*wmr).withName("wf_wmr_gpu").withParallelism(p1).build_ptr()));
     } else {
         cerr << "unknown operator " << c.op << endl;

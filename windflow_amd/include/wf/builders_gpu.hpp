@@ -257,20 +257,68 @@ public:
         return this->self();
     }
 
+    // distinct keys per replica the device-resident state is sized for (each key owns an archive area in HBM)
+    Derived& withMaxKeys(size_t n) {
+        wopt_.max_keys = n;
+        return this->self();
+    }
+    // tuples a key may keep on the device for its open windows between two batches (default: the window length for
+    // count-based windows, 1024 for time-based ones, where it depends on the rate of the stream)
+    Derived& withArchiveCapacity(size_t n) {
+        wopt_.carry_capacity = n;
+        return this->self();
+    }
+    // results per output batch (default: twice the input batch length, at least 8192)
+    Derived& withOutputCapacity(size_t n) {
+        wopt_.out_capacity = n;
+        return this->self();
+    }
+    // batch input: lane i already carries exactly the keys of replica i (no device KeyBy in front of the replicas)
+    Derived& withKeyDisjointLanes(bool b = true) {
+        wopt_.lanes_are_key_disjoint = b;
+        return this->self();
+    }
+    // count-based windows: number the tuples of a key by arrival on the device and ignore their ids (always on for batch input)
+    Derived& withRenumbering(bool b = true) {
+        wopt_.renumber = b;
+        return this->self();
+    }
+
 protected:
-    explicit GPU_Window_Builder_Base(std::string n) : GPU_Builder_Base<Derived>(std::move(n)) { this->cfg_.batch_len = 1; }
+    // withBatch(n): tuples per device batch when the operator is fed by tuples and builds its batches itself (the reference
+    // counts windows per batch, wf/builders_gpu.hpp:120; here a batch is a slice of the input stream, whatever it fires)
+    explicit GPU_Window_Builder_Base(std::string n) : GPU_Builder_Base<Derived>(std::move(n)) { this->cfg_.batch_len = 4096; }
     uint64_t win_ = 1, slide_ = 1, delay_ = 0;
     win_type_t type_ = CB;
+    gpu::WinGPUOptions wopt_;
 };
+
+namespace detail {
+// tuple / result types of a device window function: the 6-argument functor or wave_reduce(lift, combine)
+template <typename F, bool Reduce>
+struct gpu_win_types {
+    using tuple_t = typename meta::win_gpu_sig<F>::tuple_t;
+    using result_t = typename meta::win_gpu_sig<F>::result_t;
+};
+template <typename F>
+struct gpu_win_types<F, true> {
+    using tuple_t = typename meta::lift_sig<decltype(F::lift)>::tuple_t;
+    using result_t = typename meta::lift_sig<decltype(F::lift)>::result_t;
+};
+template <typename F>
+using gpu_win_types_t = gpu_win_types<F, gpu::is_wave_reduce_t<F>::value>;
+}  // namespace detail
 
 template <typename F>
 class WinSeqGPU_Builder : public GPU_Window_Builder_Base<WinSeqGPU_Builder<F>> {
 public:
-    using tuple_t = typename meta::win_gpu_sig<F>::tuple_t;
-    using result_t = typename meta::win_gpu_sig<F>::result_t;
+    using tuple_t = typename detail::gpu_win_types_t<F>::tuple_t;
+    using result_t = typename detail::gpu_win_types_t<F>::result_t;
     using winseq_t = Win_Seq_GPU<tuple_t, result_t>;
     explicit WinSeqGPU_Builder(F func) : GPU_Window_Builder_Base<WinSeqGPU_Builder<F>>("win_seq_gpu"), func_(std::move(func)) {}
-    winseq_t* build_ptr() { return new winseq_t(func_, this->win_, this->slide_, this->delay_, this->type_, this->name_, this->cfg_, this->closing_); }
+    winseq_t* build_ptr() {
+        return new winseq_t(func_, this->win_, this->slide_, this->delay_, this->type_, this->name_, this->cfg_, this->closing_, this->wopt_);
+    }
     winseq_t build() { return *std::unique_ptr<winseq_t>(build_ptr()); }
     std::unique_ptr<winseq_t> build_unique() { return std::unique_ptr<winseq_t>(build_ptr()); }
 
@@ -281,8 +329,8 @@ private:
 namespace detail {
 template <typename T, bool IsOp>
 struct gpu_farm_input_types {
-    using tuple_t = typename meta::win_gpu_sig<T>::tuple_t;
-    using result_t = typename meta::win_gpu_sig<T>::result_t;
+    using tuple_t = typename gpu_win_types_t<T>::tuple_t;
+    using result_t = typename gpu_win_types_t<T>::result_t;
 };
 template <typename A, typename B>
 struct gpu_farm_input_types<Pane_Farm_GPU<A, B>, true> {
@@ -325,7 +373,7 @@ public:
             return new keyfarm_t(*input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->closing_, routing_, opt_);
         else
             return new keyfarm_t(input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->cfg_,
-                                 this->closing_, routing_);
+                                 this->closing_, routing_, this->wopt_);
     }
     keyfarm_t build() { return *std::unique_ptr<keyfarm_t>(build_ptr()); }
     std::unique_ptr<keyfarm_t> build_unique() { return std::unique_ptr<keyfarm_t>(build_ptr()); }
@@ -375,7 +423,7 @@ public:
             return new winfarm_t(*input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->closing_, ordered_, opt_);
         else
             return new winfarm_t(input_, this->win_, this->slide_, this->delay_, this->type_, this->parallelism_, this->name_, this->cfg_,
-                                 this->closing_, ordered_);
+                                 this->closing_, ordered_, this->wopt_);
     }
     winfarm_t build() { return *std::unique_ptr<winfarm_t>(build_ptr()); }
     std::unique_ptr<winfarm_t> build_unique() { return std::unique_ptr<winfarm_t>(build_ptr()); }
@@ -400,8 +448,8 @@ namespace detail {
 // tuple / result types of a two-stage GPU operator from whichever stage is a host function
 template <typename F, typename G, bool FirstIsGPU>
 struct two_stage_gpu_types {
-    using tuple_t = typename meta::win_gpu_sig<F>::tuple_t;
-    using result_t = typename meta::win_gpu_sig<F>::result_t;
+    using tuple_t = typename gpu_win_types_t<F>::tuple_t;
+    using result_t = typename gpu_win_types_t<F>::result_t;
 };
 template <typename F, typename G>
 struct two_stage_gpu_types<F, G, false> {
@@ -443,14 +491,14 @@ protected:
 template <typename F, typename G>
 class PaneFarmGPU_Builder : public GPU_TwoStage_Builder_Base<PaneFarmGPU_Builder<F, G>> {
 public:
-    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_win_func<F>()>;
+    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_stage_func<F>()>;
     using tuple_t = typename types::tuple_t;
     using result_t = typename types::result_t;
     using panefarm_t = Pane_Farm_GPU<tuple_t, result_t>;
     PaneFarmGPU_Builder(F plq, G wlq) : GPU_TwoStage_Builder_Base<PaneFarmGPU_Builder<F, G>>("pane_farm_gpu"), plq_(std::move(plq)), wlq_(std::move(wlq)) {}
     panefarm_t* build_ptr() {
         auto* p = new panefarm_t(plq_, wlq_, this->win_, this->slide_, this->delay_, this->type_, this->par1_, this->par2_, this->name_, this->cfg_,
-                                 this->closing_, this->ordered_, this->opt_);
+                                 this->closing_, this->ordered_, this->opt_, this->wopt_);
         if (this->nesting_) p->setPrepared4Nesting();
         return p;
     }
@@ -465,7 +513,7 @@ private:
 template <typename F, typename G>
 class WinMapReduceGPU_Builder : public GPU_TwoStage_Builder_Base<WinMapReduceGPU_Builder<F, G>> {
 public:
-    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_win_func<F>()>;
+    using types = detail::two_stage_gpu_types<F, G, meta::is_gpu_stage_func<F>()>;
     using tuple_t = typename types::tuple_t;
     using result_t = typename types::result_t;
     using wmr_t = Win_MapReduce_GPU<tuple_t, result_t>;
@@ -474,7 +522,7 @@ public:
     }
     wmr_t* build_ptr() {
         auto* p = new wmr_t(map_, reduce_, this->win_, this->slide_, this->delay_, this->type_, this->par1_, this->par2_, this->name_, this->cfg_,
-                            this->closing_, this->ordered_, this->opt_);
+                            this->closing_, this->ordered_, this->opt_, this->wopt_);
         if (this->nesting_) p->setPrepared4Nesting();
         return p;
     }

@@ -42,8 +42,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// n_dev (optional): the number of valid elements lives in device memory (at most n_upper, which sizes the grid)
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    exclusive_scan_u32_kernel(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total, unsigned long long* ws) {
+    exclusive_scan_u32_kernel(const uint32_t* in, uint32_t* out, uint32_t n_upper, uint32_t* total, unsigned long long* ws,
+                              const uint32_t* n_dev = nullptr) {
+    uint32_t n = n_upper;
+    if (n_dev != nullptr) {
+        const uint32_t nd = *n_dev;
+        n = nd < n_upper ? nd : n_upper;
+    }
     __shared__ uint32_t s_wave[BLOCK_THREADS / WAVE];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_base;
@@ -117,10 +124,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-inline void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, unsigned long long* ws, hipStream_t s) {
+inline void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, unsigned long long* ws, hipStream_t s,
+                               const uint32_t* n_dev = nullptr) {
     WF_HIP_CHECK(hipMemsetAsync(ws, 0, scan_workspace_words(n) * sizeof(unsigned long long), s));
     const unsigned grid = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(exclusive_scan_u32_kernel, dim3(grid ? grid : 1), dim3(BLOCK_THREADS), 0, s, in, out, (uint32_t)n, total, ws);
+    hipLaunchKernelGGL(exclusive_scan_u32_kernel, dim3(grid ? grid : 1), dim3(BLOCK_THREADS), 0, s, in, out, (uint32_t)n, total, ws, n_dev);
 }
 
 // ---------------------------------------------------------------------------

@@ -35,7 +35,7 @@ protected:
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t N = par_;
         flat_factory_ = [=](rt::Graph& g) {
-            std::vector<rt::Node*> reps;
+            std::vector<WinEngineNodes> reps;
             for (size_t i = 0; i < N; i++) {
                 WinParams p;
                 p.win_len = win;
@@ -95,7 +95,10 @@ public:
         StageSpec s;
         s.name = name_;
         s.routing = COMPLEX;
-        s.replicas = flat_factory_(g);
+        for (const WinEngineNodes& e : flat_factory_(g)) {
+            s.replicas.push_back(e.entry);
+            s.outputs.push_back(e.output);
+        }
         s.make_emitter = [rf, N](rt::Graph& gr, size_t) { return single_emitter(gr, new KF_Emitter<tuple_t>(rf, N), N); };
         s.make_ordering = window_ordering<tuple_t>(type_, name_);
         return {s};
@@ -114,7 +117,7 @@ private:
     opt_level_t opt_;
     TwoStage_Operator<tuple_t, result_t>* inner_ = nullptr;
     std::pair<size_t, size_t> inner_par_{0, 0};
-    std::function<std::vector<rt::Node*>(rt::Graph&)> flat_factory_;
+    std::function<std::vector<WinEngineNodes>(rt::Graph&)> flat_factory_;
 };
 
 }  // namespace wf

@@ -55,9 +55,9 @@ protected:
                 p.winType = type;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, i, P, pane);
                 p.role = PLQ;
-                rt::Node* n = plq_maker(g, p, prefix + "_plq", P, i);
-                grp.first_entries.push_back(n);
-                grp.first_outputs.push_back(n);
+                const WinEngineNodes n = plq_maker(g, p, prefix + "_plq", P, i);
+                grp.first_entries.push_back(n.entry);
+                grp.first_outputs.push_back(n.output);
             }
             grp.first_emitter_tb = [=](rt::Graph& gr, size_t off) {
                 if (P == 1) return single_emitter(gr, new Standard_Emitter<tuple_t>(1), 1, off);
@@ -76,7 +76,9 @@ protected:
                 p.winType = CB;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, k, W, slide_w);
                 p.role = WLQ;
-                grp.second.push_back(wlq_maker(g, p, prefix + "_wlq", W, k));
+                const WinEngineNodes n = wlq_maker(g, p, prefix + "_wlq", W, k);
+                grp.second.push_back(n.entry);
+                grp.second_outputs.push_back(n.output);
             }
             grp.second_emitter = [=](rt::Graph& gr, size_t off) {
                 if (W == 1) return single_emitter(gr, new Standard_Emitter<result_t>(1), 1, off);

@@ -36,7 +36,8 @@ struct NestCtx {
 struct TwoStageGroup {
     std::vector<rt::Node*> first_entries;  // node receiving the input of each first-stage replica
     std::vector<rt::Node*> first_outputs;  // node emitting the output of each first-stage replica
-    std::vector<rt::Node*> second;         // second-stage replicas
+    std::vector<rt::Node*> second;         // second-stage replicas (entry nodes)
+    std::vector<rt::Node*> second_outputs; // node emitting the output of each second-stage replica (empty: same as `second`)
     // emitter into the first stage for time-based / count-based windows; leaves are
     // numbered dest_offset + local index
     std::function<EmitterAssembly(rt::Graph&, size_t dest_offset)> first_emitter_tb;
@@ -100,7 +101,11 @@ inline std::vector<StageSpec> assemble_two_stage(rt::Graph& g, std::vector<TwoSt
     b.name = name + "_stage2";
     b.routing = COMPLEX;
     b.internal = true;
-    for (auto& gr : groups) b.replicas.insert(b.replicas.end(), gr.second.begin(), gr.second.end());
+    for (auto& gr : groups) {
+        b.replicas.insert(b.replicas.end(), gr.second.begin(), gr.second.end());
+        const auto& outs = gr.second_outputs.empty() ? gr.second : gr.second_outputs;
+        b.outputs.insert(b.outputs.end(), outs.begin(), outs.end());
+    }
     b.make_emitter = [shared, off1, off2, G](rt::Graph& gr, size_t src) {
         size_t j = 0;
         while (j + 1 < G && src >= off1[j + 1]) j++;
@@ -125,12 +130,19 @@ inline std::vector<StageSpec> assemble_two_stage(rt::Graph& g, std::vector<TwoSt
 // A window engine maker builds one replica of a window stage for given parameters.
 // Operators are written against makers so that the same composition logic serves
 // the CPU engines (Win_Seq_Node) and the GPU ones (Win_Seq_GPU_Node).
-using win_engine_maker_t = std::function<rt::Node*(rt::Graph&, const WinParams&, const std::string& name, size_t par, size_t idx)>;
+// A replica may be a short chain of fused nodes (a GPU engine followed by its device->host and un-batching adapters):
+// `entry` receives the tuples, `output` emits the results.
+struct WinEngineNodes {
+    rt::Node* entry = nullptr;
+    rt::Node* output = nullptr;
+};
+using win_engine_maker_t = std::function<WinEngineNodes(rt::Graph&, const WinParams&, const std::string& name, size_t par, size_t idx)>;
 
 template <typename in_t, typename out_t, typename F>
 inline win_engine_maker_t cpu_win_engine(F func, meta::closing_func_t closing, std::shared_ptr<StatsHub> hub) {
-    return [func, closing, hub](rt::Graph& g, const WinParams& p, const std::string& name, size_t par, size_t idx) -> rt::Node* {
-        return g.adopt(new Win_Seq_Node<in_t, out_t, F>(func, p, name, par, idx, closing, hub));
+    return [func, closing, hub](rt::Graph& g, const WinParams& p, const std::string& name, size_t par, size_t idx) -> WinEngineNodes {
+        rt::Node* n = g.adopt(new Win_Seq_Node<in_t, out_t, F>(func, p, name, par, idx, closing, hub));
+        return {n, n};
     };
 }
 

@@ -57,15 +57,15 @@ protected:
                 p.role = MAP;
                 p.map_first = i;
                 p.map_stride = M;
-                rt::Node* seq = map_maker(g, p, prefix + "_map", M, i);
+                const WinEngineNodes seq = map_maker(g, p, prefix + "_map", M, i);
                 if (type == CB) {
                     rt::Node* drop = g.adopt(new WinMap_Dropper<tuple_t>(i, M));
-                    g.connect_fused(drop, drop->add_out_port(), seq);
+                    g.connect_fused(drop, drop->add_out_port(), seq.entry);
                     grp.first_entries.push_back(drop);
                 } else {
-                    grp.first_entries.push_back(seq);
+                    grp.first_entries.push_back(seq.entry);
                 }
-                grp.first_outputs.push_back(seq);
+                grp.first_outputs.push_back(seq.output);
             }
             grp.first_emitter_tb = [=](rt::Graph& gr, size_t off) { return single_emitter(gr, new WinMap_Emitter<tuple_t>(type, M), M, off); };
             grp.first_emitter_cb = [=](rt::Graph& gr, size_t off) { return single_emitter(gr, new Broadcast_Emitter<tuple_t>(M), M, off); };
@@ -78,7 +78,9 @@ protected:
                 p.winType = CB;
                 p.config = WinOperatorConfig(ctx.id, ctx.n, ctx.slide_outer, k, R, M);
                 p.role = REDUCE;
-                grp.second.push_back(reduce_maker(g, p, prefix + "_reduce", R, k));
+                const WinEngineNodes n = reduce_maker(g, p, prefix + "_reduce", R, k);
+                grp.second.push_back(n.entry);
+                grp.second_outputs.push_back(n.output);
             }
             grp.second_emitter = [=](rt::Graph& gr, size_t off) {
                 if (R == 1) return single_emitter(gr, new Standard_Emitter<result_t>(1), 1, off);
