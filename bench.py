@@ -24,7 +24,9 @@ import torch.distributed as dist  # noqa: E402
 BASELINES = {
     "map_filter": 147.5e6,  # stateless Map_GPU peak, results.org:144
     "win_agg": 118.6e6,     # keyed/stateful Map_GPU peak, results.org:126 (no windowed number is published)
+    "win_seq": 118.6e6,     # same: the reference publishes nothing for Win_Seq_GPU / Win_Farm_GPU
 }
+KEY_DISTS = {"roundrobin": 0, "uniform": 1, "zipf": 2}
 
 
 def parse_args():
@@ -36,21 +38,32 @@ def parse_args():
                    help="wait for every step's results before feeding the next one (default: the K timed steps are streamed "
                         "back to back and the timed region ends when the last one has drained)")
     p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "win_agg"),
-                   help="win_agg: keyed sliding-window aggregation (flagship); map_filter: stateless Map_GPU+Filter_GPU")
+                   help="win_agg: keyed sliding-window aggregation, Key_FFAT_GPU (flagship); win_seq: non-incremental windows, "
+                        "Key_Farm_GPU with an opaque window function (count-based win 1024 / slide 128 unless --win/--slide; --keys 1 = the "
+                        "single-key configuration); map_filter: stateless Map_GPU+Filter_GPU")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
     p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", "0")),
                    help="tuples per batch; default 128 Ki with 4 batches in flight per lane (dp: the throughput plateau at half "
                         "the latency of 256 Ki x 6), 256 Ki x 6 for keyby (one fat aggregation lane wants large kernels)")
     p.add_argument("--keys", type=int, default=int(os.environ.get("WF_BENCH_KEYS", str(1 << 20))),
                    help="distinct keys per GPU (all resident in HBM)")
-    p.add_argument("--win", type=int, default=16, help="window length, in tuples of one key")
-    p.add_argument("--slide", type=int, default=4, help="window slide, in tuples of one key")
+    p.add_argument("--win", type=int, default=0, help="window length, in tuples of one key (default 16; win_seq: 1024)")
+    p.add_argument("--slide", type=int, default=0, help="window slide, in tuples of one key (default 4; win_seq: 128)")
     p.add_argument("--count-based", action="store_true", help="count-based instead of time-based windows")
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(256 * 1024 * 1024))),
                    help="tuples fed per GPU per step (default 256 Mi: a step lasts ~0.2 s, so the driver's 20 steps time 4-5 s and ~40 000 batches)")
     p.add_argument("--inflight", type=int, default=0)
     p.add_argument("--agg-replicas", type=int, default=int(os.environ.get("WF_BENCH_AGG_REPLICAS", "0")),
                    help="keyby mode: Key_FFAT_GPU replicas behind the exchange (0: default)")
+    p.add_argument("--key-dist", default=os.environ.get("WF_BENCH_KEY_DIST", "roundrobin"), choices=sorted(KEY_DISTS),
+                   help="how the sources draw keys: roundrobin (ascending, one tuple per key per round: the friendliest stream), uniform "
+                        "random, or zipf (reference: src/GPU_Tests/zipf.hpp)")
+    p.add_argument("--zipf-alpha", type=float, default=1.3)
+    p.add_argument("--shared-keys", action="store_true",
+                   help="every source emits every key (default: sources own disjoint key sets), which puts the device KeyBy in front of "
+                        "the keyed operator")
+    p.add_argument("--replicas", type=int, default=0, help="win_seq: Key_Farm_GPU replicas (0: one per source)")
+    p.add_argument("--wave-reduce", action="store_true", help="win_seq: give the operator wave_reduce(lift, combine) instead of the opaque functor")
     p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
     p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "dp"), choices=["dp", "keyby"],
                    help="dp: keys are partitioned at ingestion, every GPU aggregates its own sources; "
@@ -188,6 +201,10 @@ def run_exchange_probe(args, world, limit_s=90):
 
 def main():
     args = parse_args()
+    if args.win <= 0:
+        args.win = 1024 if args.pipeline == "win_seq" else 16
+    if args.slide <= 0:
+        args.slide = 128 if args.pipeline == "win_seq" else 4
     if args.batch <= 0:
         args.batch = 256 * 1024 if args.parallelism == "keyby" else 128 * 1024
     if args.inflight <= 0:
@@ -242,8 +259,19 @@ def main():
             from windflow_amd import parallel as wfpar
 
             transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
-        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source, win, slide, not args.count_based, 0, args.inflight,
-                                  transport, args.agg_replicas)
+        # n_keys: per source when the sources own disjoint key sets, the whole key space (of this GPU) when they share it
+        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source * args.sources if args.shared_keys else keys_per_source,
+                                  win, slide, not args.count_based, 0, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
+                                  args.zipf_alpha, args.shared_keys)
+    elif args.pipeline == "win_seq":
+        # BASELINE.json config 3: count-based sliding windows, non-incremental user function.  A single key cannot be split
+        # over sources that own disjoint key sets: every source then emits it and one replica aggregates
+        shared = args.shared_keys or args.keys < args.sources
+        replicas = args.replicas or (min(args.sources, max(1, args.keys)) if shared else 0)
+        # n_keys: per source when the sources own disjoint key sets, the whole key space when they share it
+        pipe = ext.WinSeqPipeline(local_rank, args.sources, args.batch, max(1, args.keys) if shared else max(1, args.keys // args.sources),
+                                  args.win, args.slide, False, args.inflight, replicas, args.wave_reduce, KEY_DISTS[args.key_dist],
+                                  args.zipf_alpha, shared)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 
@@ -291,13 +319,18 @@ def main():
             "p99_latency_us": float(lat.item()),
             "p50_latency_us": stats["latency_p50_us"],
             "config": {
-                "model": "Key_FFAT_GPU keyed sliding-window sum" if args.pipeline == "win_agg" else args.pipeline,
+                "model": {"win_agg": "Key_FFAT_GPU keyed sliding-window sum",
+                          "win_seq": "Key_Farm_GPU non-incremental sliding-window sum (%s)" % ("wave_reduce" if args.wave_reduce else "opaque functor")}
+                .get(args.pipeline, args.pipeline),
                 "global_batch": tuples_per_step_gpu * world,
                 "seq_len": args.batch,
                 "parallelism": "%s%d" % (args.parallelism, world),
                 "sources_per_gpu": args.sources,
-                "keys_per_gpu": keys_per_source * args.sources,
-                "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if args.count_based else "TB", args.win, args.slide),
+                "keys_per_gpu": args.keys if args.pipeline == "win_seq" else keys_per_source * args.sources,
+                "key_distribution": args.key_dist + (" alpha=%g" % args.zipf_alpha if args.key_dist == "zipf" else ""),
+                "shared_keys": bool(args.shared_keys or (args.pipeline == "win_seq" and args.keys < args.sources)),
+                "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if (args.count_based or args.pipeline == "win_seq") else "TB", args.win, args.slide),
+                "latency_samples": stats.get("latency_samples"),
                 "steps_streamed": "drained after every step" if args.drain_every_step else "back to back, drained once at the end of the timed region",
                 "sink_results_rank0": stats["sink_tuples"],
                 "overflow": stats.get("overflow", 0),

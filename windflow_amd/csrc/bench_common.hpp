@@ -3,13 +3,16 @@
 // gpu_map_stateful.cpp:80-85), a fast synthetic generator, and the step gate /
 // barrier that lets a driver time "K steps" on a persistent streaming graph.
 #pragma once
+#include <cmath>
 #include <cstdlib>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include <wf/basic.hpp>
 #include <wf/context.hpp>
@@ -99,15 +102,59 @@ struct StepBarrier {
     }
 };
 
+// How a generator draws the key of the next tuple.  The reference's studies use round-robin keys and, in some runs, a
+// zipf generator (/root/reference/src/GPU_Tests/zipf.hpp:14-21, results.org:111); round-robin in ascending order is the
+// friendliest stream there is (every batch arrives sorted, one tuple per key), so the unfriendly ones are first-class here.
+enum key_dist_t { KEYS_ROUNDROBIN = 0, KEYS_UNIFORM = 1, KEYS_ZIPF = 2 };
+struct KeySpace {
+    size_t n_keys = 1;
+    int dist = KEYS_ROUNDROBIN;
+    double zipf_alpha = 1.3;
+    bool shared = false;  // every source draws from the same key set (a KeyBy is then needed in front of keyed operators)
+    // zipf: quantile table of the distribution, rank r has probability ~ 1 / (r+1)^alpha (2^20 quantiles, built once)
+    std::shared_ptr<std::vector<uint32_t>> quantiles;
+    static constexpr int QBITS = 20;
+    void prepare() {
+        if (dist != KEYS_ZIPF || quantiles) return;
+        const size_t n = n_keys, q = size_t(1) << QBITS;
+        std::vector<double> cdf(n);
+        long double acc = 0;
+        for (size_t r = 0; r < n; r++) {
+            acc += std::pow((double)(r + 1), -zipf_alpha);
+            cdf[r] = (double)acc;
+        }
+        auto tab = std::make_shared<std::vector<uint32_t>>(q);
+        size_t r = 0;
+        for (size_t i = 0; i < q; i++) {
+            const double u = ((double)i + 0.5) / (double)q * (double)acc;
+            while (r + 1 < n && cdf[r] < u) r++;
+            (*tab)[i] = (uint32_t)r;
+        }
+        quantiles = tab;
+    }
+    static KeySpace make(size_t n_keys, int dist = KEYS_ROUNDROBIN, double alpha = 1.3, bool shared = false) {
+        KeySpace k;
+        k.n_keys = n_keys ? n_keys : 1;
+        k.dist = dist;
+        k.zipf_alpha = alpha;
+        k.shared = shared;
+        k.prepare();
+        return k;
+    }
+};
+
 // Bulk generator functor for Batch_Source:  bool(tuple_t*, size_t cap, size_t& n, RuntimeContext&)
-// keys are drawn round-robin-with-stride so every key receives in-order ids, ts is
-// a monotone per-source microsecond clock.
+// round-robin keys receive in-order per-key ids; with random keys id is the per-source sequence number (count-based
+// windows then number the tuples of a key by arrival on the device); ts is a monotone per-source microsecond clock.
 class GatedGenerator {
 public:
     // src_offset / src_stride: position of this process's sources among all the sources of the job
     // (rank * n_sources, world * n_sources), so keys stay disjoint across ranks as well
     GatedGenerator(StepGate* gates, size_t n_keys, uint64_t ts_step_us, size_t n_sources, size_t src_offset = 0, size_t src_stride = 0)
-        : gates_(gates), n_keys_(n_keys), ts_step_(ts_step_us), n_sources_(src_stride ? src_stride : n_sources), src_offset_(src_offset) {}
+        : GatedGenerator(gates, KeySpace::make(n_keys), ts_step_us, n_sources, src_offset, src_stride) {}
+    GatedGenerator(StepGate* gates, KeySpace keys, uint64_t ts_step_us, size_t n_sources, size_t src_offset = 0, size_t src_stride = 0)
+        : gates_(gates), keys_(std::move(keys)), n_keys_(keys_.n_keys), ts_step_(ts_step_us), n_sources_(src_stride ? src_stride : n_sources),
+          src_offset_(src_offset) {}
 
     bool operator()(tuple_t* buf, size_t cap, size_t& n, wf::RuntimeContext& ctx) {
         StepGate& g = gates_[ctx.getReplicaIndex()];
@@ -127,34 +174,50 @@ public:
         opened_ns_ = wf::current_time_nsecs();
         const uint64_t src = ctx.getReplicaIndex() + src_offset_;
         uint64_t seq = seq_, kc = kc_, round = round_;
-        const uint64_t nk = n_keys_, ns = n_sources_, tstep = ts_step_;
+        const uint64_t nk = n_keys_, tstep = ts_step_;
+        // disjoint key sets: key % n_sources == src, per-key order is then well defined without cross-source ordering
+        const uint64_t kmul = keys_.shared ? 1 : n_sources_, kadd = keys_.shared ? 0 : src;
         const bool nt = nt_stores_;
-        // keys of different sources are disjoint (key % n_sources == src): per-key order is
-        // then well defined without cross-source ordering
+        if (rng_ == 0) rng_ = 0x9E3779B97F4A7C15ull * (src + 1);
+        uint64_t rng = rng_;
+        const int dist = keys_.dist;
+        const uint32_t* quant = keys_.quantiles ? keys_.quantiles->data() : nullptr;
         for (int64_t i = 0; i < take; i++, seq++) {
+            uint64_t k, id;
+            if (dist == KEYS_ROUNDROBIN) {
+                k = kc;
+                id = round;
+                if (++kc == nk) {
+                    kc = 0;
+                    round++;
+                }
+            } else {
+                rng ^= rng << 13;  // xorshift64
+                rng ^= rng >> 7;
+                rng ^= rng << 17;
+                k = dist == KEYS_UNIFORM ? (uint64_t)(((unsigned __int128)rng * nk) >> 64) : (uint64_t)quant[rng >> (64 - KeySpace::QBITS)];
+                id = seq;
+            }
             if (nt) {
                 // non-temporal stores: the slab is only read back by the DMA engine; not pulling its lines into the
                 // cache first saves the read-for-ownership traffic when many ranks share the host memory system
-                __builtin_nontemporal_store(kc * ns + src, &buf[i].key);
-                __builtin_nontemporal_store(round, &buf[i].id);
+                __builtin_nontemporal_store(k * kmul + kadd, &buf[i].key);
+                __builtin_nontemporal_store(id, &buf[i].id);
                 __builtin_nontemporal_store(seq * tstep, &buf[i].ts);
                 __builtin_nontemporal_store((double)(seq & 1023), &buf[i].value);
                 __builtin_nontemporal_store(1.0, &buf[i].aux);
             } else {
-                buf[i].key = kc * ns + src;
-                buf[i].id = round;
+                buf[i].key = k * kmul + kadd;
+                buf[i].id = id;
                 buf[i].ts = seq * tstep;
                 buf[i].value = (double)(seq & 1023);
                 buf[i].aux = 1.0;
-            }
-            if (++kc == nk) {
-                kc = 0;
-                round++;
             }
         }
         seq_ = seq;
         kc_ = kc;
         round_ = round;
+        rng_ = rng;
         n = (size_t)take;
         return true;
     }
@@ -165,11 +228,12 @@ public:
 
 private:
     StepGate* gates_;
+    KeySpace keys_;
     size_t n_keys_;
     uint64_t ts_step_;
     size_t n_sources_;
     size_t src_offset_ = 0;
-    uint64_t seq_ = 0, kc_ = 0, round_ = 0;
+    uint64_t seq_ = 0, kc_ = 0, round_ = 0, rng_ = 0;
     uint64_t punct_ = 0;
     uint64_t opened_ns_ = 0;
     // on by default (single GPU: same throughput, lower p99 latency; several ranks: less host memory traffic); WF_BENCH_NT_STORES=0 disables

@@ -289,13 +289,17 @@ public:
     // transport == nullptr: every source lane feeds its own Key_FFAT_GPU replica (keys are partitioned at the
     // sources).  With a transport the tuples are re-partitioned by key across the ranks first (Exchange_GPU:
     // RCCL all-to-all over xGMI) and then across the local replicas (device KeyBy).
+    // key_dist / shared_keys: how the sources draw keys (bench_common.hpp KeySpace).  With shared keys every source emits every
+    // key, so the batches go through the device KeyBy in front of the aggregation replicas.
     WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
-                   size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr, size_t agg_replicas = 0)
+                   size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr, size_t agg_replicas = 0, int key_dist = 0,
+                   double zipf_alpha = 1.3, bool shared_keys = false)
         : n_sources_(n_sources), n_sinks_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<SinkTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
-        wfbench::GatedGenerator gen(gates_.get(), n_keys, 1, n_sources, rank * n_sources, world * n_sources);
+        wfbench::GatedGenerator gen(gates_.get(), wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys), 1,
+                                    n_sources, rank * n_sources, world * n_sources);
         source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
                       .withGPUConfiguration(gpu_id).build_unique();
         MultiPipe& mp = graph_.add_source(*source_);
@@ -324,7 +328,16 @@ public:
             wcfg.max_keys = n_keys * n_sources / n_sinks_;
             wcfg.max_keys += wcfg.max_keys / 4 + 1024;
             wcfg.out_capacity = batch_len * world;
+        } else if (shared_keys) {
+            // every lane carries every key: device KeyBy (one partition kernel chain per batch) in front of the replicas
+            wcfg.lanes_are_key_disjoint = false;
+            n_sinks_ = agg_replicas ? agg_replicas : n_sources;
+            wcfg.max_keys = n_keys / n_sinks_;  // shared: n_keys is the whole key space
+            wcfg.max_keys += wcfg.max_keys / 4 + 1024;
+            wcfg.out_capacity = 2 * batch_len;  // a hot key can send a replica more than its share of a batch
+            punct_expected_ = n_sinks_ * n_sources;  // every sub-batch of a lane's punctuated batch carries the punctuation
         }
+        if (punct_expected_ == 0) punct_expected_ = n_sinks_;
         kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg));
         mp.add(*kff_);
         auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
@@ -348,14 +361,14 @@ public:
         py::gil_scoped_release rel;
         step_id_++;
         for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, tuples_per_source);
-        barrier_->wait(step_id_, (int)n_sinks_);
+        barrier_->wait(step_id_, (int)punct_expected_);
     }
     // k steps streamed back to back (no drain between them): returns when the last one has reached the sinks
     void steps(int64_t k, int64_t tuples_per_source) {
         py::gil_scoped_release rel;
         step_id_ += (uint64_t)k;
         for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, k * tuples_per_source);
-        barrier_->wait(step_id_, (int)n_sinks_);
+        barrier_->wait(step_id_, (int)punct_expected_);
     }
     void close() {
         if (closed_) return;
@@ -375,6 +388,7 @@ public:
         d["latency_p50_us"] = latency_->percentile_us(50);
         d["latency_p99_us"] = latency_->percentile_us(99);
         d["latency_mean_us"] = latency_->mean_us();
+        d["latency_samples"] = latency_->count();
         d["threads"] = graph_.getNumThreads();
         uint64_t dropped = 0, overflow = 0, skipped = 0, full = 0;
         for (auto& c : kff_->getDeviceCounters()) {
@@ -393,7 +407,7 @@ public:
     std::string dot() { return graph_.get_DOTGraph(); }
 
 private:
-    size_t n_sources_, n_sinks_;
+    size_t n_sources_, n_sinks_, punct_expected_ = 0;
     std::unique_ptr<wfbench::StepGate[]> gates_;
     PipeGraph graph_;
     std::shared_ptr<SinkTotals> totals_;
@@ -406,6 +420,227 @@ private:
     uint64_t step_id_ = 0;
     bool closed_ = false;
 };
+
+// ---------------------------------------------------------------------------
+// non-incremental GPU windows (BASELINE.json config 3): S gated batch sources -> Key_Farm_GPU -> D2H -> batch sinks
+// ---------------------------------------------------------------------------
+// the "non-incremental user kernel": an opaque sequential window function (sum of the values)
+struct WinSumGPU {
+    __host__ __device__ void operator()(uint64_t, const tuple_t* data, size_t n, result_t* res, char*, size_t) const {
+        double s = 0.0;
+        for (size_t i = 0; i < n; i++) s += data[i].value;
+        res->value = s;
+    }
+};
+// window function of the engine tests: 0 = sum, 1 = newest value, 2 = oldest value, 3 = number of tuples
+struct WinFuncByMode {
+    int mode;
+    __host__ __device__ void operator()(uint64_t, const tuple_t* data, size_t n, result_t* res, char*, size_t) const {
+        if (mode == 0) {
+            double s = 0.0;
+            for (size_t i = 0; i < n; i++) s += data[i].value;
+            res->value = s;
+        } else if (mode == 1) {
+            res->value = n ? data[n - 1].value : -1.0;
+        } else if (mode == 2) {
+            res->value = n ? data[0].value : -1.0;
+        } else {
+            res->value = (double)n;
+        }
+    }
+};
+
+class WinSeqPipeline {
+public:
+    // replicas = 0: one per source (lanes key-disjoint unless shared_keys); wave_reduce: the associative form of the same sum
+    WinSeqPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, size_t inflight,
+                   size_t replicas, bool wave_reduce, int key_dist, double zipf_alpha, bool shared_keys)
+        : n_sources_(n_sources), n_sinks_(replicas ? replicas : n_sources), gates_(new wfbench::StepGate[n_sources]),
+          graph_("win_seq_gpu", Mode::DEFAULT) {
+        auto totals = totals_ = std::make_shared<SinkTotals>();
+        auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
+        wfbench::GatedGenerator gen(gates_.get(), wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys), 1,
+                                    n_sources);
+        source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
+                      .withGPUConfiguration(gpu_id).build_unique();
+        MultiPipe& mp = graph_.add_source(*source_);
+        const bool disjoint = !shared_keys && n_sinks_ == n_sources;
+        keyby_free_ = disjoint;
+        const size_t keys_per_replica = (shared_keys ? n_keys : n_keys * n_sources) / n_sinks_;  // shared: n_keys is the whole key space
+        const size_t max_keys = keys_per_replica + keys_per_replica / 4 + 16;
+        auto configure = [&](auto builder) {
+            if (time_based)
+                builder.withTBWindows(std::chrono::microseconds(win), std::chrono::microseconds(slide));
+            else
+                builder.withCBWindows(win, slide);
+            builder.withName("key_farm_gpu").withParallelism(n_sinks_).withInFlightBatches(inflight).withGPUConfiguration(gpu_id).withMaxKeys(max_keys)
+                .withOutputCapacity(std::max<size_t>(batch_len / std::max<uint64_t>(1, time_based ? 1 : slide) + max_keys, 8192))
+                .withKeyDisjointLanes(disjoint);
+            if (time_based) builder.withArchiveCapacity((size_t)std::min<uint64_t>(2 * win + 64, 1 << 22));
+            auto op = builder.build_unique();
+            auto* raw = op.get();
+            counters_ = [raw] { return raw->getDeviceCounters(); };
+            return op;
+        };
+        if (wave_reduce)
+            op_ = configure(KeyFarmGPU_Builder(gpu::wave_reduce(wfbench::LiftValue{}, wfbench::CombSum{})));
+        else
+            op_ = configure(KeyFarmGPU_Builder(WinSumGPU{}));
+        mp.add(*op_);
+        auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
+            double s = 0.0;
+            for (size_t i = 0; i < n; i++) s += data[i].value;
+            {
+                std::lock_guard<std::mutex> l(totals->m);
+                totals->tuples += n;
+                totals->value_sum += s;
+                totals->batches += (data != nullptr);
+            }
+            if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
+        };
+        sink_ = BatchSink_Builder(sink_f).withName("sink").withParallelism(n_sinks_).build_unique();
+        mp.chain_sink(*sink_);
+        latency_ = sink_->latency();
+        graph_.start();
+    }
+    ~WinSeqPipeline() { close(); }
+    void step(int64_t tuples_per_source) { steps(1, tuples_per_source); }
+    void steps(int64_t k, int64_t tuples_per_source) {
+        py::gil_scoped_release rel;
+        step_id_ += (uint64_t)k;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, k * tuples_per_source);
+        barrier_->wait(step_id_, (int)punct_expected());
+    }
+    void close() {
+        if (closed_) return;
+        closed_ = true;
+        py::gil_scoped_release rel;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].shutdown();
+        graph_.wait_end();
+    }
+    py::dict stats() {
+        py::dict d;
+        {
+            std::lock_guard<std::mutex> l(totals_->m);
+            d["sink_tuples"] = totals_->tuples;
+            d["sink_value_sum"] = totals_->value_sum;
+            d["sink_batches"] = totals_->batches;
+        }
+        d["latency_p50_us"] = latency_->percentile_us(50);
+        d["latency_p99_us"] = latency_->percentile_us(99);
+        d["latency_mean_us"] = latency_->mean_us();
+        d["latency_samples"] = latency_->count();
+        d["threads"] = graph_.getNumThreads();
+        uint64_t dropped = 0, deferred = 0, full = 0, carry = 0;
+        for (auto& c : counters_()) {
+            dropped += c.dropped;
+            deferred += c.deferred;
+            full += c.table_full;
+            carry += c.carry_overflow;
+        }
+        d["dropped"] = dropped;
+        d["deferred_windows"] = deferred;
+        d["table_full"] = full;
+        d["carry_overflow"] = carry;
+        d["overflow"] = carry;
+        return d;
+    }
+    void reset_latency() { latency_->clear(); }
+    std::string dot() { return graph_.get_DOTGraph(); }
+
+private:
+    // every batch that carries a punctuation reaches exactly one sink when the lanes map 1:1; behind the device KeyBy every
+    // sub-batch of a punctuated batch carries it, so each sink sees one per source
+    size_t punct_expected() const { return (n_sinks_ == n_sources_ && keyby_free_) ? n_sinks_ : n_sinks_ * n_sources_; }
+    size_t n_sources_, n_sinks_;
+    bool keyby_free_ = true;
+    std::unique_ptr<wfbench::StepGate[]> gates_;
+    PipeGraph graph_;
+    std::shared_ptr<SinkTotals> totals_;
+    std::shared_ptr<wfbench::StepBarrier> barrier_;
+    std::shared_ptr<LatencyRecorder> latency_;
+    std::unique_ptr<Batch_Source<tuple_t>> source_;
+    std::unique_ptr<Basic_Operator> op_;
+    std::function<std::vector<gpu::WinCounters>()> counters_;
+    std::unique_ptr<Batch_Sink<result_t>> sink_;
+    uint64_t step_id_ = 0;
+    bool closed_ = false;
+};
+
+// WinBatchEngine driven directly (numerics tests): tuples is an [n,5] int64 array of 40-byte tuples processed in batches of
+// batch_len; returns an [m,4] int64 array of 32-byte results (key, gwid, ts, value bits) + the device counters.
+// func_mode: see WinFuncByMode; wave_reduce: evaluate sum / newest / oldest through wave_reduce(lift, CombByMode)
+static py::tuple win_batch_run(py::array_t<int64_t, py::array::c_style | py::array::forcecast> tuples, uint64_t win, uint64_t slide, uint64_t delay,
+                               bool time_based, size_t max_keys, size_t batch_len, size_t carry_capacity, size_t out_capacity, int func_mode,
+                               bool wave_reduce, bool renumber) {
+    auto buf = tuples.request();
+    if (buf.ndim != 2 || buf.shape[1] != 5) throw std::invalid_argument("tuples must be [n,5] int64");
+    const size_t n = (size_t)buf.shape[0];
+    const tuple_t* host = static_cast<const tuple_t*>(buf.ptr);
+    WF_HIP_CHECK(hipSetDevice(0));
+    gpu::Stream stream;
+    WinParams p;
+    p.win_len = win;
+    p.slide_len = slide;
+    p.triggering_delay = delay;
+    p.winType = time_based ? TB : CB;
+    p.config = WinOperatorConfig(0, 1, slide, 0, 1, slide);
+    gpu::WinGPUOptions opt;
+    opt.max_keys = max_keys;
+    opt.carry_capacity = carry_capacity;
+    opt.out_capacity = out_capacity;
+    opt.renumber = renumber;
+    std::vector<result_t> results;
+    uint64_t kernels = 0;
+    gpu::WinCounters ctr{};
+    size_t dev_bytes = 0;
+    auto run = [&](auto& engine) {
+        gpu::BatchPool in_pool(gpu::MemKind::DEVICE, 0, sizeof(tuple_t), batch_len, 2);
+        auto drain = [&](gpu::Batch* out) {
+            out->ready.record(stream);
+            stream.sync();
+            const uint32_t cnt = *out->count_mirror;
+            const size_t old = results.size();
+            results.resize(old + cnt);
+            if (cnt) WF_HIP_CHECK(hipMemcpy(results.data() + old, out->data<result_t>(), cnt * sizeof(result_t), hipMemcpyDeviceToHost));
+            out->release(stream);
+        };
+        for (size_t off = 0; off < n; off += batch_len) {
+            const size_t cnt = std::min(batch_len, n - off);
+            gpu::Batch* d = in_pool.acquire(stream);
+            d->host_hdr.count = (uint32_t)cnt;
+            WF_HIP_CHECK(hipMemcpyAsync(d->header(), &d->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, stream));
+            WF_HIP_CHECK(hipMemcpyAsync(d->data<tuple_t>(), host + off, cnt * sizeof(tuple_t), hipMemcpyHostToDevice, stream));
+            gpu::Batch* out = engine.process(d, stream, kernels);
+            d->release(stream);
+            drain(out);
+        }
+        size_t cursor = 0;
+        gpu::Batch* out = nullptr;
+        while (engine.flush_range(cursor, stream, kernels, out)) drain(out);
+        ctr = engine.read_counters(stream);
+        dev_bytes = engine.device_bytes();
+    };
+    if (wave_reduce) {
+        auto f = gpu::wave_reduce(wfbench::LiftValue{}, CombByMode{func_mode});
+        gpu::WinBatchEngine<tuple_t, result_t, decltype(f)> engine(f, p, opt, batch_len, 0, 3, 0);
+        run(engine);
+    } else {
+        gpu::WinBatchEngine<tuple_t, result_t, WinFuncByMode> engine(WinFuncByMode{func_mode}, p, opt, batch_len, 0, 3, 0);
+        run(engine);
+    }
+    py::array_t<int64_t> arr({(py::ssize_t)results.size(), (py::ssize_t)4});
+    if (!results.empty()) std::memcpy(arr.mutable_data(), results.data(), results.size() * sizeof(result_t));
+    py::dict counters;
+    counters["dropped"] = ctr.dropped;
+    counters["deferred"] = ctr.deferred;
+    counters["table_full"] = ctr.table_full;
+    counters["carry_overflow"] = ctr.carry_overflow;
+    counters["work_overflow"] = ctr.work_overflow;
+    counters["kernels"] = kernels;
+    counters["device_bytes"] = dev_bytes;
+    return py::make_tuple(arr, counters);
+}
 
 // ---------------------------------------------------------------------------
 // distributed layer
@@ -522,16 +757,31 @@ PYBIND11_MODULE(_C, m) {
     m.def("exchange_local_run", &exchange_local_run, py::arg("gpu_id"), py::arg("world"), py::arg("n_per_rank"), py::arg("n_keys"),
           py::arg("batch_len"));
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
-        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t>(),
+        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t, int, double,
+                      bool>(),
              py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"),
              py::arg("time_based") = false, py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr,
-             py::arg("agg_replicas") = 0)
+             py::arg("agg_replicas") = 0, py::arg("key_dist") = 0, py::arg("zipf_alpha") = 1.3, py::arg("shared_keys") = false)
         .def("step", &WinAggPipeline::step)
         .def("steps", &WinAggPipeline::steps)
         .def("close", &WinAggPipeline::close)
         .def("stats", &WinAggPipeline::stats)
         .def("reset_latency", &WinAggPipeline::reset_latency)
         .def("dot", &WinAggPipeline::dot);
+    m.def("win_batch_run", &win_batch_run, py::arg("tuples"), py::arg("win"), py::arg("slide"), py::arg("delay"), py::arg("time_based"),
+          py::arg("max_keys"), py::arg("batch_len"), py::arg("carry_capacity") = 0, py::arg("out_capacity") = 0, py::arg("func_mode") = 0,
+          py::arg("wave_reduce") = false, py::arg("renumber") = false);
+    py::class_<WinSeqPipeline>(m, "WinSeqPipeline")
+        .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, size_t, size_t, bool, int, double, bool>(), py::arg("gpu_id"),
+             py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"), py::arg("time_based") = false,
+             py::arg("inflight") = 4, py::arg("replicas") = 0, py::arg("wave_reduce") = false, py::arg("key_dist") = 0, py::arg("zipf_alpha") = 1.3,
+             py::arg("shared_keys") = false)
+        .def("step", &WinSeqPipeline::step)
+        .def("steps", &WinSeqPipeline::steps)
+        .def("close", &WinSeqPipeline::close)
+        .def("stats", &WinSeqPipeline::stats)
+        .def("reset_latency", &WinSeqPipeline::reset_latency)
+        .def("dot", &WinSeqPipeline::dot);
     py::class_<MapFilterPipeline>(m, "MapFilterPipeline")
         .def(py::init<int, size_t, size_t, size_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"),
              py::arg("inflight") = 6)

@@ -124,6 +124,7 @@ struct WinRun {
     uint64_t first_lwid;  // first window fired by this batch
     uint64_t keep_from;   // state before the batch: ordinals below belong to no open window
     uint64_t base_count;  // state before the batch: tuples received
+    uint64_t initial;     // first ordinal of the key's first window on this replica
     uint32_t dense;
     uint32_t pad;
 };
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         run.first_lwid = st.next_lwid;
         run.keep_from = wa.initial_id + st.next_lwid * g.slide;
         run.base_count = st.count;
+        run.initial = wa.initial_id;
         run.dense = st.dense;
         run.pad = 0;
         runs[r] = run;
@@ -280,7 +282,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 runs[r].unsorted = 1;
                 if (j > start) atomicMax((unsigned long long*)&runs[r].max_ord, (unsigned long long)prev);  // a local maximum
             }
-            if (ord < runs[r].keep_from && runs[r].first_lwid > 0) atomicAdd(&ctr->dropped, 1u);
+            // late: older than every window still open (tuples in the gaps between hopping windows are not late, just unused)
+            if (ord < runs[r].keep_from && runs[r].first_lwid > 0 &&
+                (g.win >= g.slide || (ord >= runs[r].initial && (ord - runs[r].initial) % g.slide < g.win)))
+                atomicAdd(&ctr->dropped, 1u);
         }
         if (j == start + runs[r].len - 1) atomicMax((unsigned long long*)&runs[r].max_ord, (unsigned long long)ord);
         work[dst] = t;
