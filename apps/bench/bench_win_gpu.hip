@@ -4,7 +4,9 @@
 // flavours side by side, on count-based sliding windows with a window sum.
 //
 //   bench_win_gpu -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide]
-//                 [-b windows per GPU batch] [-t seconds]
+//                 [-b tuples per GPU batch] [-t seconds] [-B]
+// -B feeds the flat GPU operators (kf_gpu, wf_gpu, kff_gpu) with batches instead of tuples: Batch_Source lanes that own
+// disjoint key sets -> operator -> Batch_Sink, the stream never leaves pinned / device memory.
 #include <unistd.h>
 
 #include <atomic>
@@ -100,13 +102,36 @@ struct TimedSource {
     }
 };
 
+// -B: every source owns `n_keys` keys (key % n_sources == source), round-robin with progressive ids, filled a batch at a time
+struct TimedBatchSource {
+    size_t n_keys, n_sources;
+    uint64_t stop_at_us;
+    std::atomic<uint64_t>* generated;
+    uint64_t seq = 0;
+    bool operator()(tuple_t* buf, size_t cap, size_t& n, RuntimeContext& ctx) {
+        const uint64_t src = ctx.getReplicaIndex();
+        uint64_t s = seq;
+        for (size_t i = 0; i < cap; i++, s++) {
+            buf[i].key = (s % n_keys) * n_sources + src;
+            buf[i].id = s / n_keys;
+            buf[i].ts = buf[i].id;
+            buf[i].value = (int64_t)(s & 1023);
+        }
+        seq = s;
+        n = cap;
+        generated->fetch_add(cap, std::memory_order_relaxed);
+        return current_time_usecs() < stop_at_us;
+    }
+};
+
 int main(int argc, char** argv) {
     std::string op = "kf_gpu";
-    size_t sources = 2, replicas = 4, keys = 64, batch = 1024;
+    bool batch_fed = false;
+    size_t sources = 2, replicas = 4, keys = 64, batch = 4096;
     uint64_t win = 1024, slide = 128;
     double seconds = 3.0;
     int c;
-    while ((c = getopt(argc, argv, "o:s:n:k:w:l:b:t:")) != -1) {
+    while ((c = getopt(argc, argv, "o:s:n:k:w:l:b:t:B")) != -1) {
         switch (c) {
             case 'o': op = optarg; break;
             case 's': sources = std::strtoull(optarg, nullptr, 10); break;
@@ -116,6 +141,7 @@ int main(int argc, char** argv) {
             case 'l': slide = std::strtoull(optarg, nullptr, 10); break;
             case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
             case 't': seconds = std::atof(optarg); break;
+            case 'B': batch_fed = true; break;
             default:
                 std::cout << argv[0] << " -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide] "
                           << "[-b batch] [-t seconds]" << std::endl;
@@ -128,6 +154,42 @@ int main(int argc, char** argv) {
         return 3;
     }
     std::atomic<uint64_t> generated{0}, results{0};
+    if (batch_fed) {
+        if (op != "kf_gpu" && op != "wf_gpu" && op != "kff_gpu") {
+            std::cerr << "-B needs a flat GPU operator (kf_gpu, wf_gpu, kff_gpu)" << std::endl;
+            return 2;
+        }
+        const size_t keys_per_source = std::max<size_t>(1, keys / sources);
+        if (batch < 4096) batch = 1 << 17;
+        PipeGraph graph("bench_" + op + "_batches", Mode::DEFAULT);
+        const uint64_t t0 = current_time_usecs();
+        TimedBatchSource gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), &generated};
+        auto src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).build_unique();
+        MultiPipe& mp = graph.add_source(*src);
+        const bool disjoint = replicas == sources;
+        const size_t max_keys = keys_per_source * sources / (disjoint ? sources : 1) * 5 / 4 + 64;
+        const size_t out_cap = batch / slide + max_keys + 8192;
+        std::unique_ptr<Basic_Operator> oper;
+        if (op == "kf_gpu")
+            oper = KeyFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)
+                       .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        else if (op == "wf_gpu")
+            oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)
+                       .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        else
+            oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)
+                       .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        mp.add(*oper);
+        auto sink = BatchSink_Builder([&results](const result_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
+                        .withName("sink").withParallelism(replicas).build_unique();
+        mp.chain_sink(*sink);
+        graph.run();
+        const double elapsed = (current_time_usecs() - t0) / 1e6;
+        std::cout << op << " [batch-fed] sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " win=" << win
+                  << " slide=" << slide << " batch=" << batch << " : " << (double)generated.load() / elapsed << " tuples/s ("
+                  << (double)results.load() / elapsed << " windows/s), elapsed " << elapsed << " s" << std::endl;
+        return 0;
+    }
     const size_t keys_per_source = std::max<size_t>(1, keys);  // every source produces all the keys
     PipeGraph graph("bench_" + op, Mode::DETERMINISTIC);  // count-based windows need ordered input
     const uint64_t t0 = current_time_usecs();

@@ -25,6 +25,7 @@ BASELINES = {
     "map_filter": 147.5e6,  # stateless Map_GPU peak, results.org:144
     "win_agg": 118.6e6,     # keyed/stateful Map_GPU peak, results.org:126 (no windowed number is published)
     "win_seq": 118.6e6,     # same: the reference publishes nothing for Win_Seq_GPU / Win_Farm_GPU
+    "ysb": None,            # Yahoo Streaming Benchmark: harness only, no published number
 }
 KEY_DISTS = {"roundrobin": 0, "uniform": 1, "zipf": 2}
 
@@ -40,7 +41,11 @@ def parse_args():
     p.add_argument("--pipeline", default=os.environ.get("WF_BENCH_PIPELINE", "win_agg"),
                    help="win_agg: keyed sliding-window aggregation, Key_FFAT_GPU (flagship); win_seq: non-incremental windows, "
                         "Key_Farm_GPU with an opaque window function (count-based win 1024 / slide 128 unless --win/--slide; --keys 1 = the "
-                        "single-key configuration); map_filter: stateless Map_GPU+Filter_GPU")
+                        "single-key configuration); ysb: Yahoo Streaming Benchmark on the device (filter, join, 10 s tumbling count per "
+                        "campaign; with --parallelism keyby the campaigns are partitioned across the GPUs by Exchange_GPU); map_filter: "
+                        "stateless Map_GPU+Filter_GPU")
+    p.add_argument("--ysb-period-us", type=int, default=1, help="ysb: event-time distance between two events of a source")
+    p.add_argument("--ysb-delay-us", type=int, default=1000000, help="ysb: triggering delay of the windows (tolerated lag between sources)")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
     p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", "0")),
                    help="tuples per batch; default 128 Ki with 4 batches in flight per lane (dp: the throughput plateau at half "
@@ -272,6 +277,14 @@ def main():
         pipe = ext.WinSeqPipeline(local_rank, args.sources, args.batch, max(1, args.keys) if shared else max(1, args.keys // args.sources),
                                   args.win, args.slide, False, args.inflight, replicas, args.wave_reduce, KEY_DISTS[args.key_dist],
                                   args.zipf_alpha, shared)
+    elif args.pipeline == "ysb":
+        transport = None
+        if args.parallelism == "keyby":
+            from windflow_amd import parallel as wfpar
+
+            transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
+        pipe = ext.YsbPipeline(local_rank, args.sources, args.batch, args.ysb_period_us, args.ysb_delay_us, args.inflight,
+                               args.agg_replicas or 1, transport)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 
@@ -304,7 +317,7 @@ def main():
         value = total_tuples / elapsed
         base = BASELINES.get(args.pipeline)
         print(json.dumps({
-            "metric": "input tuples/sec (whole node)",
+            "metric": "input events/sec (whole node)" if args.pipeline == "ysb" else "input tuples/sec (whole node)",
             "value": value,
             "unit": "tuples/s",
             "n_gpus": world,
@@ -314,12 +327,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": (value / base) if base else None,
-            "dtype": "fp64 values / u64 keys (40-byte tuples)",
+            "dtype": "u64 / u32 fields (56-byte events)" if args.pipeline == "ysb" else "fp64 values / u64 keys (40-byte tuples)",
             "data": "synthetic tuple stream generated on the host (random-free, deterministic)",
             "p99_latency_us": float(lat.item()),
             "p50_latency_us": stats["latency_p50_us"],
             "config": {
                 "model": {"win_agg": "Key_FFAT_GPU keyed sliding-window sum",
+                          "ysb": "Yahoo Streaming Benchmark: Filter_GPU -> Map_GPU(join) -> Key_FFAT_GPU 10 s tumbling count per campaign",
                           "win_seq": "Key_Farm_GPU non-incremental sliding-window sum (%s)" % ("wave_reduce" if args.wave_reduce else "opaque functor")}
                 .get(args.pipeline, args.pipeline),
                 "global_batch": tuples_per_step_gpu * world,
@@ -335,6 +349,7 @@ def main():
                 "sink_results_rank0": stats["sink_tuples"],
                 "overflow": stats.get("overflow", 0),
                 "dropped": stats.get("dropped", 0),
+                **({"counted_views_rank0": stats["counted_views"], "tuple_bytes": 56} if args.pipeline == "ysb" else {}),
             },
             **({"keyby_exchange_probe": probe} if probe is not None else {}),
         }), flush=True)

@@ -13,6 +13,13 @@ from windflow_amd import build as wfbuild
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(scope="module")
+def ext():
+    import windflow_amd
+
+    return windflow_amd.load_ext()
+
+
 def run_app(name, args, hip=False, timeout=110):
     src = os.path.join(ROOT, "apps", "ysb", name + (".hip" if hip else ".cpp"))
     exe = wfbuild.build_cpp(src, os.path.join(ROOT, "apps", "bin", name), hip=hip, extra=["-I" + os.path.dirname(src)])
@@ -37,7 +44,25 @@ def test_ysb_cpu(app, n, m):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,m,batch", [(1, 1, 4096), (2, 2, 10000)])
-def test_ysb_gpu(n, m, batch):
-    got = run_app("ysb_gpu", ["-e", 2_500_000, "-p", 10, "-n", n, "-m", m, "-b", batch], hip=True)
+@pytest.mark.parametrize("n,m,batch,engine", [(1, 1, 4096, "ffat"), (2, 2, 10000, "ffat"), (3, 1, 65536, "ffat"), (2, 2, 8192, "farm")])
+def test_ysb_gpu(n, m, batch, engine):
+    """the whole query on the device; a triggering delay longer than the stream makes the result independent of how the
+    source lanes interleave (the windows fire at end of stream)"""
+    got = run_app("ysb_gpu", ["-e", 2_500_000, "-p", 10, "-n", n, "-m", m, "-b", batch, "-d", 30_000_000, "-w", engine], hip=True)
     assert got == expected(2_500_000, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sources,replicas", [(2, 1), (3, 2)])
+def test_ysb_pipeline_steps(ext, sources, replicas):
+    """the pipeline bench.py drives: gated steps, closed-form oracle"""
+    per_source, period = 1_200_000, 10
+    pipe = ext.YsbPipeline(0, sources, 16384, period, 30_000_000, 4, replicas)
+    pipe.step(per_source)
+    pipe.step(per_source)
+    pipe.close()
+    st = pipe.stats()
+    exp = expected(2 * per_source, sources, period)
+    assert st["counted_views"] == exp["events counted in windows"]
+    assert st["sink_tuples"] == exp["received results"]
+    assert st["dropped"] == 0 and st["overflow"] == 0 and st["table_full"] == 0

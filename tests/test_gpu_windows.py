@@ -131,6 +131,37 @@ def test_key_ffat_time_based_matches_oracle(ext, n, n_keys, win, slide, batch, t
         assert got[k][0] == pytest.approx(s, abs=1e-9)
 
 
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("n,n_keys,win,slide,batch", [
+    (30000, 100, 10, 10, 4096),    # tumbling
+    (30000, 3, 64, 64, 2048),      # tumbling, long runs (wave-per-run path)
+    (40000, 700, 4, 12, 8192),     # hopping: pane 4, a window every 3 panes
+    (30000, 2, 6, 10, 1000),       # hopping, pane 2, long runs
+    (20000, 5, 1, 1, 512),         # every tuple its own window
+])
+def test_key_ffat_tumbling_and_hopping(ext, tb, n, n_keys, win, slide, batch):
+    """slide >= win (the reference's Key_FFAT_GPU refuses them, key_ffat.hpp:132-135): pane = gcd, the tree is one pane wide"""
+    if tb:
+        n_keys = min(n_keys, 70)  # timestamps are global: with many keys every tuple would span hundreds of (empty) windows of its key
+    t, vals = make_stream(n, n_keys, seed=n + win + slide)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, tb, max(16, n_keys), batch, 1 << 17)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0
+    got = unpack(res)
+    assert len(got) == len(res)
+    n_exp = 0
+    for key in np.unique(t[:, 0]):
+        m = t[:, 0] == key
+        v, ts = vals[m], t[m, 2]
+        ords = ts if tb else np.arange(len(v))
+        lw = 0
+        while lw * slide <= int(ords.max()):
+            sel = (ords >= lw * slide) & (ords < lw * slide + win)
+            assert got[(int(key), lw)][0] == pytest.approx(float(v[sel].sum()), abs=1e-9), (key, lw)
+            lw += 1
+            n_exp += 1
+    assert len(got) == n_exp
+
+
 def test_key_ffat_skewed_keys(ext):
     t, vals = make_stream(60000, 2000, seed=5, skew=True)
     res, ctr = ext.key_ffat_run(t, 20, 5, 0, False, 4096, 16384)

@@ -42,10 +42,11 @@ def build_extension(force=False, verbose=True):
     """Compile windflow_amd/_C*.so (pybind11 + HIP kernels) if missing or stale."""
     out = ext_path()
     srcs = [os.path.join(CSRC, "wf_ext.hip")]
-    deps = [INCLUDE, CSRC]
+    deps = [INCLUDE, CSRC, os.path.join(os.path.dirname(ROOT), "apps", "ysb")]
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_mtime(deps):
         return out
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC,
+           "-I" + os.path.join(os.path.dirname(ROOT), "apps", "ysb")]
     cmd += _pybind_includes() + srcs + ["-o", out, "-lpthread"]
     rccl_inc = "/opt/rocm/include/rccl"
     if os.path.isdir(rccl_inc):

@@ -17,6 +17,7 @@
 #include <wf/windflow_gpu.hpp>
 
 #include "bench_common.hpp"
+#include "ysb_gpu_common.hpp"  // apps/ysb
 
 namespace py = pybind11;
 using namespace wf;
@@ -643,6 +644,178 @@ static py::tuple win_batch_run(py::array_t<int64_t, py::array::c_style | py::arr
 }
 
 // ---------------------------------------------------------------------------
+// Yahoo! Streaming Benchmark on the device (BASELINE.json config 5), driven step by step:
+//   S gated event sources -> Filter_GPU -> Map_GPU (join) -> [Exchange_GPU across ranks] -> device KeyBy
+//     -> Key_FFAT_GPU (10 s tumbling windows per campaign) -> D2H -> batch sinks
+// Events carry a synthetic clock (`period_us` between the events of a source), so a run is reproducible and the number
+// of views every window must count is known in closed form.
+// ---------------------------------------------------------------------------
+class GatedEventSource {
+public:
+    GatedEventSource(wfbench::StepGate* gates, const ysb::Campaigns* c, uint64_t period_us) : gates_(gates), period_(period_us), n_ads_(c->n_ads()) {
+        ads_ = std::make_shared<std::vector<uint64_t>>(n_ads_);
+        for (size_t i = 0; i < n_ads_; i++) (*ads_)[i] = c->ad(i);
+    }
+    bool operator()(ysb::Event* buf, size_t cap, size_t& n, wf::RuntimeContext& ctx) {
+        wfbench::StepGate& g = gates_[ctx.getReplicaIndex()];
+        punct_ = 0;
+        int64_t take = 0;
+        {
+            std::unique_lock<std::mutex> l(g.m);
+            g.cv.wait(l, [&] { return g.quota > 0 || g.stop; });
+            if (g.quota <= 0 && g.stop) {
+                n = 0;
+                return false;
+            }
+            take = g.quota < (int64_t)cap ? g.quota : (int64_t)cap;
+            g.quota -= take;
+            if (g.quota == 0) punct_ = g.step_id;
+        }
+        opened_ns_ = wf::current_time_nsecs();
+        uint64_t v = value_;
+        const uint64_t* ads = ads_->data();
+        for (int64_t i = 0; i < take; i++, v++) {
+            ysb::Event& e = buf[i];
+            const uint64_t x = v % 100000;
+            e.ts = v * period_;
+            e.seq = v;
+            e.ad_id = ads[x % n_ads_];
+            e.user_id = 0;
+            e.page_id = 0;
+            e.ad_type = (uint32_t)(x % 5);
+            e.event_type = (uint32_t)(x % 3);
+            e.ip = 1;
+        }
+        value_ = v;
+        n = (size_t)take;
+        return true;
+    }
+    uint64_t punctuation() const { return punct_; }
+    uint64_t opened_ns() const { return opened_ns_; }
+
+private:
+    wfbench::StepGate* gates_;
+    uint64_t period_;
+    size_t n_ads_;
+    std::shared_ptr<std::vector<uint64_t>> ads_;
+    uint64_t value_ = 0, punct_ = 0, opened_ns_ = 0;
+};
+
+struct YsbTotals {
+    std::mutex m;
+    uint64_t results = 0, views = 0, batches = 0;
+};
+
+class YsbPipeline {
+public:
+    YsbPipeline(int gpu_id, size_t n_sources, size_t batch_len, uint64_t period_us, uint64_t delay_us, size_t inflight, size_t agg_replicas,
+                std::shared_ptr<dist::Transport> transport = nullptr)
+        : n_sources_(n_sources), n_sinks_(agg_replicas ? agg_replicas : 1), gates_(new wfbench::StepGate[n_sources]),
+          graph_("ysb_gpu", Mode::DEFAULT) {
+        auto totals = totals_ = std::make_shared<YsbTotals>();
+        auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
+        const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
+        source_ = BatchSource_Builder(GatedEventSource(gates_.get(), &campaigns_, period_us)).withName("ysb_source").withParallelism(n_sources)
+                      .withBatch(batch_len).withInFlightBatches(inflight).withGPUConfiguration(gpu_id).build_unique();
+        MultiPipe& mp = graph_.add_source(*source_);
+        filter_ = FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                      .withGPUConfiguration(gpu_id).build_unique();
+        mp.add(*filter_);
+        join_ = MapGPU_Builder(ysb::JoinGPU(campaigns_)).withName("ysb_join_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                    .withGPUConfiguration(gpu_id).build_unique();
+        mp.chain(*join_);
+        punct_expected_ = n_sinks_ * n_sources;  // the device KeyBy copies a lane's punctuation to every replica
+        if (transport) {
+            exchange_ = ExchangeGPU_Builder<ysb::Joined>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
+                            .withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
+            mp.add(*exchange_);
+            punct_expected_ = n_sinks_;  // the exchange merges the punctuations of a step into one
+        }
+        agg_ = KeyFFATGPU_Builder(ysb::CountLift(), ysb::CountCombine()).withTBWindows(us(ysb::WINDOW_US), us(ysb::WINDOW_US), us(delay_us))
+                   .withName("ysb_kff_gpu").withParallelism(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).withMaxKeys(256)
+                   .withOutputCapacity(8192).build_unique();
+        mp.add(*agg_);
+        auto sink_f = [totals, barrier](const ysb::WinResult* data, size_t n, const gpu::BatchHeader& h) {
+            uint64_t res = 0, views = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (data[i].count == 0) continue;
+                res++;
+                views += data[i].count;
+            }
+            {
+                std::lock_guard<std::mutex> l(totals->m);
+                totals->results += res;
+                totals->views += views;
+                totals->batches += (data != nullptr);
+            }
+            if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
+        };
+        sink_ = BatchSink_Builder(sink_f).withName("ysb_sink").withParallelism(n_sinks_).build_unique();
+        mp.chain_sink(*sink_);
+        latency_ = sink_->latency();
+        graph_.start();
+    }
+    ~YsbPipeline() { close(); }
+    void step(int64_t events_per_source) { steps(1, events_per_source); }
+    void steps(int64_t k, int64_t events_per_source) {
+        py::gil_scoped_release rel;
+        step_id_ += (uint64_t)k;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].release(step_id_, k * events_per_source);
+        barrier_->wait(step_id_, (int)punct_expected_);
+    }
+    void close() {
+        if (closed_) return;
+        closed_ = true;
+        py::gil_scoped_release rel;
+        for (size_t i = 0; i < n_sources_; i++) gates_[i].shutdown();
+        graph_.wait_end();
+    }
+    py::dict stats() {
+        py::dict d;
+        {
+            std::lock_guard<std::mutex> l(totals_->m);
+            d["sink_tuples"] = totals_->results;
+            d["counted_views"] = totals_->views;
+            d["sink_batches"] = totals_->batches;
+        }
+        d["latency_p50_us"] = latency_->percentile_us(50);
+        d["latency_p99_us"] = latency_->percentile_us(99);
+        d["latency_mean_us"] = latency_->mean_us();
+        d["latency_samples"] = latency_->count();
+        d["threads"] = graph_.getNumThreads();
+        uint64_t dropped = 0, overflow = 0, full = 0;
+        for (auto& c : agg_->getDeviceCounters()) {
+            dropped += c.dropped;
+            overflow += c.overflow;
+            full += c.table_full;
+        }
+        d["dropped"] = dropped;
+        d["overflow"] = overflow;
+        d["table_full"] = full;
+        return d;
+    }
+    void reset_latency() { latency_->clear(); }
+    std::string dot() { return graph_.get_DOTGraph(); }
+
+private:
+    size_t n_sources_, n_sinks_, punct_expected_ = 0;
+    ysb::Campaigns campaigns_;
+    std::unique_ptr<wfbench::StepGate[]> gates_;
+    PipeGraph graph_;
+    std::shared_ptr<YsbTotals> totals_;
+    std::shared_ptr<wfbench::StepBarrier> barrier_;
+    std::shared_ptr<LatencyRecorder> latency_;
+    std::unique_ptr<Batch_Source<ysb::Event>> source_;
+    std::unique_ptr<Filter_GPU<ysb::Event>> filter_;
+    std::unique_ptr<Map_GPU<ysb::Event, ysb::Joined>> join_;
+    std::unique_ptr<Exchange_GPU<ysb::Joined>> exchange_;
+    std::unique_ptr<Key_FFAT_GPU<ysb::Joined, ysb::WinResult>> agg_;
+    std::unique_ptr<Batch_Sink<ysb::WinResult>> sink_;
+    uint64_t step_id_ = 0;
+    bool closed_ = false;
+};
+
+// ---------------------------------------------------------------------------
 // distributed layer
 // ---------------------------------------------------------------------------
 static py::bytes rccl_create_id() { return py::bytes(dist::RcclTransport::create_id()); }
@@ -782,6 +955,16 @@ PYBIND11_MODULE(_C, m) {
         .def("stats", &WinSeqPipeline::stats)
         .def("reset_latency", &WinSeqPipeline::reset_latency)
         .def("dot", &WinSeqPipeline::dot);
+    py::class_<YsbPipeline>(m, "YsbPipeline")
+        .def(py::init<int, size_t, size_t, uint64_t, uint64_t, size_t, size_t, std::shared_ptr<dist::Transport>>(), py::arg("gpu_id"),
+             py::arg("n_sources"), py::arg("batch_len"), py::arg("period_us") = 1, py::arg("delay_us") = 1000000, py::arg("inflight") = 4,
+             py::arg("agg_replicas") = 1, py::arg("transport") = nullptr)
+        .def("step", &YsbPipeline::step)
+        .def("steps", &YsbPipeline::steps)
+        .def("close", &YsbPipeline::close)
+        .def("stats", &YsbPipeline::stats)
+        .def("reset_latency", &YsbPipeline::reset_latency)
+        .def("dot", &YsbPipeline::dot);
     py::class_<MapFilterPipeline>(m, "MapFilterPipeline")
         .def(py::init<int, size_t, size_t, size_t, size_t>(), py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"),
              py::arg("inflight") = 6)

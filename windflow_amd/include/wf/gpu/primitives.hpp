@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     __shared__ uint32_t s_wave[BLOCK_THREADS / WAVE];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_base;
-    if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(&ws[0], 1ull);
+    // ws == nullptr: the caller guarantees a single tile (n_upper <= SCAN_TILE): no ticket, no look-back, no workspace to clear
+    if (threadIdx.x == 0) s_tile = ws ? (uint32_t)atomicAdd(&ws[0], 1ull) : blockIdx.x;
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     if (wave == 0) {
         uint32_t exclusive = 0;
         if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(&desc[0], DESC_INC | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && ws) __hip_atomic_store(&desc[0], DESC_INC | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (lane == 0) __hip_atomic_store(&desc[tile], DESC_AGG | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int look = (int)tile - 1;
@@ -126,6 +127,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 inline void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, unsigned long long* ws, hipStream_t s,
                                const uint32_t* n_dev = nullptr) {
+    if (n <= (size_t)SCAN_TILE) {  // one tile: nothing to coordinate
+        hipLaunchKernelGGL(exclusive_scan_u32_kernel, dim3(1), dim3(BLOCK_THREADS), 0, s, in, out, (uint32_t)n, total, (unsigned long long*)nullptr, n_dev);
+        return;
+    }
     WF_HIP_CHECK(hipMemsetAsync(ws, 0, scan_workspace_words(n) * sizeof(unsigned long long), s));
     const unsigned grid = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(exclusive_scan_u32_kernel, dim3(grid ? grid : 1), dim3(BLOCK_THREADS), 0, s, in, out, (uint32_t)n, total, ws, n_dev);

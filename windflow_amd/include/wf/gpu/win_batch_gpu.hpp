@@ -451,6 +451,60 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// LDS-tiled form of the same evaluation, used whenever a window fits the tile: consecutive windows of a key overlap by
+// win - slide tuples, so a workgroup takes `group` consecutive windows, stages the span they cover -
+// (group - 1) * slide + win tuples - in LDS ONCE with all its 256 threads (coalesced 8-byte loads), and `group` threads then
+// run the user's function on the staged copy: the sequential loop of an opaque functor pays LDS latency per tuple instead
+// of a trip to L2 / HBM, and every tuple is fetched once per group instead of once per window it belongs to.  (The
+// reference's K1 reads every window from global memory, win_seq_gpu.hpp:56-80.)  A group whose span does not fit (windows
+// of different keys far apart, the end-of-stream flush over scattered carry areas) falls back to global pointers.
+constexpr uint32_t WB_TILE_BYTES = 64 * 1024;
+template <typename T, typename R, typename F>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    wb_eval_tile_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, uint32_t group, char* scratch,
+                        size_t scratch_size, F f) {
+    extern __shared__ __align__(16) char wb_tile_smem[];
+    __shared__ unsigned long long s_lo, s_hi;
+    // staged in the widest words the tuple type is aligned to
+    typedef std::conditional_t<alignof(T) % 8 == 0, uint64_t, std::conditional_t<alignof(T) % 4 == 0, uint32_t, uint8_t>> raw_word_t;
+    typedef raw_word_t __attribute__((may_alias)) word_t;
+    constexpr uint32_t TILE_TUPLES = WB_TILE_BYTES / sizeof(T);
+    T* tile = reinterpret_cast<T*>(wb_tile_smem);
+    uint32_t n_win = ctl->win_total;
+    if (n_win > out_cap) n_win = out_cap;
+    const uint32_t n_groups = (n_win + group - 1) / group;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    char* my_scratch = scratch_size ? scratch + (size_t)tid * scratch_size : nullptr;
+    for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+        const uint32_t w0 = gi * group;
+        const uint32_t cnt = n_win - w0 < group ? n_win - w0 : group;
+        if (threadIdx.x == 0) {
+            s_lo = ~0ull;
+            s_hi = 0ull;
+        }
+        __syncthreads();
+        WinDesc d{};
+        const bool mine = threadIdx.x < cnt;
+        if (mine) {
+            d = desc[w0 + threadIdx.x];
+            atomicMin(&s_lo, (unsigned long long)d.off);
+            atomicMax(&s_hi, (unsigned long long)(d.off + d.len));
+        }
+        __syncthreads();
+        const uint64_t lo = s_lo, hi = s_hi;
+        const bool fits = hi >= lo && hi - lo <= (uint64_t)TILE_TUPLES;
+        if (fits) {
+            const word_t* src = reinterpret_cast<const word_t*>(base + lo);
+            word_t* dst = reinterpret_cast<word_t*>(tile);
+            const uint32_t words = (uint32_t)(hi - lo) * (uint32_t)(sizeof(T) / sizeof(raw_word_t));
+            for (uint32_t k = threadIdx.x; k < words; k += BLOCK_THREADS) dst[k] = src[k];
+        }
+        __syncthreads();
+        if (mine) f(d.gwid, fits ? static_cast<const T*>(tile + (d.off - lo)) : base + d.off, (size_t)d.len, &out[w0 + threadIdx.x], my_scratch, scratch_size);
+        __syncthreads();
+    }
+}
+
 // wave_reduce(lift, combine): one wave64 per window.  Every lane lifts and folds WR_PER_LANE consecutive tuples (the wave
 // reads 64 * WR_PER_LANE consecutive tuples per round: coalesced), an order-preserving shuffle tree folds the 64 partial
 // results, rounds are folded left to right: the combine only has to be associative.
@@ -692,6 +746,21 @@ public:
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(WinCounters), init.get()));
         if (scratch_size_ > 0) scratch_.resize((size_t)EVAL_GRID * BLOCK_THREADS * scratch_size_);
+        // windows per workgroup of the LDS-tiled evaluation: as many consecutive windows as share one 64 KB tile (0: a window
+        // alone does not fit, evaluate from global memory).  Time-based windows are sized as if a key ticked once per time unit,
+        // bounded by what a key can carry; a group that turns out larger than the tile falls back to global memory by itself.
+        {
+            const uint64_t tile_tuples = WB_TILE_BYTES / sizeof(T);
+            uint64_t w = g_.win, sl = g_.slide;
+            if (g_.is_tb && w > g_.carry_cap) {
+                sl = std::max<uint64_t>(1, sl * g_.carry_cap / w);
+                w = g_.carry_cap;
+            }
+            if (w <= tile_tuples) tile_group_ = (uint32_t)std::min<uint64_t>(BLOCK_THREADS, (tile_tuples - w) / sl + 1);
+            if (const char* e = std::getenv("WF_WIN_TILE")) {
+                if (std::atoi(e) == 0) tile_group_ = 0;
+            }
+        }
         init.sync();
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), g_.out_cap, pool_slabs));
@@ -797,6 +866,10 @@ private:
         if constexpr (is_wave_reduce_t<F>::value) {
             hipLaunchKernelGGL((wb_eval_reduce_kernel<T, R, decltype(func_.lift), decltype(func_.comb)>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base,
                                desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, func_.lift, func_.comb);
+        } else if (tile_group_ > 0) {
+            const unsigned groups = (unsigned)((g_.out_cap + tile_group_ - 1) / tile_group_);
+            hipLaunchKernelGGL((wb_eval_tile_kernel<T, R, F>), dim3(std::min(groups, EVAL_GRID)), dim3(BLOCK_THREADS), WB_TILE_BYTES, s, base,
+                               desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, tile_group_, scratch_.data(), scratch_size_, func_);
         } else {
             hipLaunchKernelGGL((wb_eval_kernel<T, R, F>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base, desc_.data(), out->template data<R>(),
                                ctl_.data(), g_.out_cap, scratch_.data(), scratch_size_, func_);
@@ -809,6 +882,7 @@ private:
     WinGeometry g_{};
     size_t table_cap_ = 0, batch_cap_ = 0, n_tab_ = 0;
     int slot_bits_ = 0;
+    uint32_t tile_group_ = 0;
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<WinKeyState> states_;
     DeviceBuffer<T> carry_, work_;
