@@ -16,6 +16,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("WF_QUIET", "1")  # stdout carries the JSON line only (the runtime's banner goes there otherwise)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -70,12 +71,13 @@ def parse_args():
     p.add_argument("--replicas", type=int, default=0, help="win_seq: Key_Farm_GPU replicas (0: one per source)")
     p.add_argument("--wave-reduce", action="store_true", help="win_seq: give the operator wave_reduce(lift, combine) instead of the opaque functor")
     p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
-    p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "dp"), choices=["dp", "keyby"],
-                   help="dp: keys are partitioned at ingestion, every GPU aggregates its own sources; "
-                        "keyby: tuples are re-partitioned by key across GPUs with Exchange_GPU (RCCL all-to-all over xGMI)")
-    p.add_argument("--exchange-probe-steps", type=int, default=int(os.environ.get("WF_BENCH_EXCHANGE_PROBE", "3")),
-                   help="N>1, dp mode: after the timed run, also time this many steps of the keyby pipeline (reported as an "
-                        "extra field; 0 disables)")
+    p.add_argument("--parallelism", default=os.environ.get("WF_BENCH_PARALLELISM", "auto"), choices=["auto", "dp", "keyby"],
+                   help="keyby: tuples are re-partitioned by key across the GPUs with Exchange_GPU (RCCL all-to-all over xGMI) - what "
+                        "a keyed operator needs when the sources cannot pre-partition; dp: keys are partitioned at ingestion, every GPU "
+                        "aggregates its own sources and no byte crosses xGMI; auto: keyby when N > 1 (win_agg, ysb), dp on one GPU")
+    p.add_argument("--dp-probe-steps", type=int, default=int(os.environ.get("WF_BENCH_DP_PROBE", "3")),
+                   help="N>1, keyby mode: after the timed run, also time this many steps of the dp pipeline (no exchange) in child "
+                        "processes and report them as an extra field (0 disables)")
     return p.parse_args()
 
 
@@ -160,8 +162,9 @@ def timed_steps(pipe, per_source, steps, barrier, drain_every_step=False):
     return time.perf_counter() - t0
 
 
-def run_exchange_probe(args, world, limit_s=90):
-    """Time a few steps of the keyby pipeline in a child process; returns a small dict for the JSON line."""
+def run_dp_probe(args, world, limit_s=90):
+    """Time a few steps of the dp pipeline (keys partitioned at ingestion, no exchange) in a child process; returns a small
+    dict for the JSON line.  It is the upper bound the keyby number is compared with."""
     import subprocess
 
     env = dict(os.environ)
@@ -170,13 +173,13 @@ def run_exchange_probe(args, world, limit_s=90):
     # the children rendezvous among themselves: rank 0's child hosts the store on the new port (under torchrun the
     # workers would otherwise look for the launcher's store there)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.exchange_probe_steps), "--warmup", "1",
-           "--parallelism", "keyby", "--exchange-probe-steps", "0", "--pipeline", "win_agg", "--sources", str(args.sources),
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.dp_probe_steps), "--warmup", "1",
+           "--parallelism", "dp", "--dp-probe-steps", "0", "--pipeline", args.pipeline, "--sources", str(args.sources),
            "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
            "--tuples-per-step", str(args.tuples_per_step), "--no-cpu-partition"]
     if args.count_based:
         cmd.append("--count-based")
-    print("[bench] timed run done; probing the keyby exchange in a child process (limit %d s)" % limit_s, file=sys.stderr, flush=True)
+    print("[bench] timed run done; timing the dp pipeline (no exchange) in a child process (limit %d s)" % limit_s, file=sys.stderr, flush=True)
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     t_end = time.time() + limit_s
     while True:
@@ -188,16 +191,10 @@ def run_exchange_probe(args, world, limit_s=90):
                 child.kill()
                 out, err = child.communicate()
                 return {"status": "timeout", "stderr_tail": (err or "")[-300:]}
-            print("[bench] exchange probe still running", file=sys.stderr, flush=True)
-
-    class R:  # noqa: D401 - tiny result holder
-        pass
-
-    r = R()
-    r.returncode, r.stdout, r.stderr = child.returncode, out, err
-    if r.returncode != 0:
-        return {"status": "failed (exit %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
-    for line in reversed(r.stdout.splitlines()):
+            print("[bench] dp probe still running", file=sys.stderr, flush=True)
+    if child.returncode != 0:
+        return {"status": "failed (exit %d)" % child.returncode, "stderr_tail": (err or "")[-300:]}
+    for line in reversed(out.splitlines()):
         if line.startswith("{"):
             d = json.loads(line)
             return {"status": "ok", "tuples_per_s": d["value"], "steps": d["steps"], "p99_latency_us": d["p99_latency_us"]}
@@ -206,14 +203,19 @@ def run_exchange_probe(args, world, limit_s=90):
 
 def main():
     args = parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.parallelism == "auto":
+        # on several GPUs the headline is the pipeline that really couples them: the keyed operator sits behind the
+        # cross-GPU KeyBy.  Pipelines without an exchange stage (win_seq, map_filter) are data-parallel by construction.
+        args.parallelism = "keyby" if (world_env > 1 and args.pipeline in ("win_agg", "ysb")) else "dp"
     if args.win <= 0:
         args.win = 1024 if args.pipeline == "win_seq" else 16
     if args.slide <= 0:
         args.slide = 128 if args.pipeline == "win_seq" else 4
     if args.batch <= 0:
-        args.batch = 256 * 1024 if args.parallelism == "keyby" else 128 * 1024
+        args.batch = 128 * 1024
     if args.inflight <= 0:
-        args.inflight = 6 if args.parallelism == "keyby" else 4
+        args.inflight = 4
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,13 +307,12 @@ def main():
         dist.all_reduce(lat, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # Secondary measurement (never part of `value`): the same job with the cross-GPU KeyBy exchange in the data
-    # path.  It runs in CHILD processes (one per rank, own rendezvous port) under a wall-clock limit, so that a
-    # fabric problem - an RCCL abort, a hang inside a collective - cannot take the headline number down.
+    # Secondary measurement (never part of `value`): the same job without the exchange (keys partitioned at ingestion),
+    # in CHILD processes (one per rank, own rendezvous port) under a wall-clock limit.
     probe = None
-    if (world > 1 or os.environ.get("WF_BENCH_FORCE_PROBE")) and args.pipeline == "win_agg" and args.parallelism == "dp" \
-            and args.exchange_probe_steps > 0:
-        probe = run_exchange_probe(args, world)
+    if (world > 1 or os.environ.get("WF_BENCH_FORCE_PROBE")) and args.pipeline in ("win_agg", "ysb") and args.parallelism == "keyby" \
+            and args.dp_probe_steps > 0:
+        probe = run_dp_probe(args, world)
     if rank == 0:
         total_tuples = tuples_per_step_gpu * world * args.steps
         value = total_tuples / elapsed
@@ -351,7 +352,9 @@ def main():
                 "dropped": stats.get("dropped", 0),
                 **({"counted_views_rank0": stats["counted_views"], "tuple_bytes": 56} if args.pipeline == "ysb" else {}),
             },
-            **({"keyby_exchange_probe": probe} if probe is not None else {}),
+            **({"exchange": {k[len("exchange_"):]: stats[k] for k in sorted(stats) if k.startswith("exchange_")}}
+               if "exchange_rounds" in stats else {}),
+            **({"dp_no_exchange_probe": probe} if probe is not None else {}),
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

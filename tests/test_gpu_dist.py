@@ -9,17 +9,29 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,n,keys,batch", [(2, 40_000, 101, 2048), (3, 60_000, 1000, 4096), (4, 30_000, 7, 1024)])
-def test_exchange_conserves_and_routes(ext, world, n, keys, batch):
-    res = ext.exchange_local_run(0, world, n, keys, batch)
-    sent = [n * (r + 1) // world for r in range(world)]
+@pytest.mark.parametrize("world,n,keys,batch,sources,lanes,per_round", [
+    (2, 40_000, 101, 2048, 1, 1, 0),
+    (3, 60_000, 1000, 4096, 1, 1, 0),
+    (4, 30_000, 7, 1024, 1, 1, 0),
+    (1, 50_000, 300, 2048, 3, 4, 0),     # one rank: the exchange is the device KeyBy, merging the lanes' batches
+    (1, 20_000, 50, 1024, 2, 1, 0),      # one rank, one lane: batches pass through
+    (2, 60_000, 500, 2048, 4, 3, 0),     # several batches per round, several lanes behind the exchange
+    (3, 40_000, 64, 1024, 2, 4, 0),
+    (2, 40_000, 500, 2048, 4, 2, 1),     # one batch per round
+    (4, 30_000, 3, 512, 4, 2, 0),        # three keys per source: most (rank, lane) destinations stay empty, a few are hot
+])
+def test_exchange_conserves_and_routes(ext, world, n, keys, batch, sources, lanes, per_round):
+    res = ext.exchange_local_run(0, world, n, keys, batch, sources, lanes, per_round)
+    sent = [sources * max(1, n * (r + 1) // world) for r in range(world)]
     assert sum(r[0] for r in res) == sum(sent)
-    exp_sum = sum(float(np.sum(np.arange(s) % 97)) for s in sent)
+    exp_sum = sum(sources * float(np.sum(np.arange(s // sources) % 97)) for s in sent)
     assert sum(r[1] for r in res) == pytest.approx(exp_sum)
-    assert all(r[2] == 0 for r in res), "tuples delivered to a rank that does not own their key"
+    assert all(r[2] == 0 for r in res), "tuples delivered to a (rank, lane) that does not own their key"
     assert all(r[3] == 0 for r in res), "per-key FIFO order broken by the exchange"
     if keys >= 100:
         assert all(r[0] > 0 for r in res)
+    if per_round == 1 and world > 1:
+        assert all(r[5] <= r[4] for r in res), "more input batches than rounds although a round may carry only one"
 
 
 def test_rccl_world1_collectives(ext):

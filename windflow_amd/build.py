@@ -101,18 +101,23 @@ PROGRAMS = [
 ]
 
 
-def build_programs(verbose=True):
-    """Compile every native program that exists in the tree (stale ones only)."""
-    built = []
-    for src, out, hip in PROGRAMS:
+def build_programs(verbose=True, jobs=None):
+    """Compile every native program that exists in the tree (stale ones only), a few at a time."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs = jobs or int(os.environ.get("MAX_JOBS", "0")) or min(6, os.cpu_count() or 1)
+
+    def one(prog):
+        src, out, hip = prog
         s, o = os.path.join(REPO, src), os.path.join(REPO, out)
         if not os.path.exists(s):
-            continue
-        extra = ["-I" + os.path.dirname(s)]
+            return None
         if verbose:
             print("[windflow_amd.build] program", src, flush=True)
-        built.append(build_cpp(s, o, hip=hip, extra=extra))
-    return built
+        return build_cpp(s, o, hip=hip, extra=["-I" + os.path.dirname(s)])
+
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        return [b for b in pool.map(one, PROGRAMS) if b]
 
 
 if __name__ == "__main__":

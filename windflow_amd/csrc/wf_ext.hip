@@ -283,6 +283,18 @@ static uint32_t exclusive_scan(uintptr_t in, uintptr_t out, size_t n) {
     return t;
 }
 
+static void exchange_stats(py::dict& d, const ExchangeStats& x, size_t lanes) {
+    d["exchange_rounds"] = x.rounds;
+    d["exchange_empty_rounds"] = x.empty_rounds;
+    d["exchange_batches_in"] = x.bundles;
+    d["exchange_batches_out"] = x.lane_batches;
+    d["exchange_tuples_sent"] = x.tuples_sent;
+    d["exchange_tuples_received"] = x.tuples_received;
+    d["exchange_max_link_bytes_per_round"] = x.max_link_bytes_per_round;
+    d["exchange_rounds_per_s"] = x.elapsed_us ? (double)x.rounds * 1e6 / (double)x.elapsed_us : 0.0;
+    d["exchange_lanes"] = lanes;
+}
+
 // S gated batch sources -> Key_FFAT_GPU (device-resident keyed sliding-window sum) -> D2H -> batch sinks
 // (BASELINE.json config 4, the flagship "sliding-window aggregation" pipeline)
 class WinAggPipeline {
@@ -317,18 +329,19 @@ public:
         cfg.batch_len = batch_len;
         cfg.pool_slabs = inflight;
         if (transport) {
-            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources).withGPUConfiguration(gpu_id)
-                            .withInFlightBatches(inflight).build_unique();
+            // the exchange delivers `lanes` key-disjoint streams (owner rank, then lane inside the rank, both from the key hash):
+            // one aggregation replica per lane, no second partitioning pass behind the all-to-all
+            n_sinks_ = agg_replicas ? agg_replicas : std::min<size_t>(n_sources, 4);
+            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
+                            .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
             mp.add(*exchange_);
-            wcfg.lanes_are_key_disjoint = false;
-            // hash partitioning is only balanced on average: leave headroom in the per-replica key tables and
-            // in the result batches (a replica may see up to world x batch_len tuples in one batch)
-            // behind the exchange every batch holds a whole round (up to world x batch_len tuples): a few fat
-            // aggregation replicas keep the kernels large; many thin ones would drown in launches
-            n_sinks_ = agg_replicas ? agg_replicas : 1;  // measured on one MI355X: 1 replica 844 M t/s, 2: 559, 4: 507, 8: 304
+            wcfg.lanes_are_key_disjoint = true;
+            // hash partitioning is only balanced on average: leave headroom in the per-replica key tables and in the
+            // result batches (a lane receives what `world` ranks send it in a round)
             wcfg.max_keys = n_keys * n_sources / n_sinks_;
             wcfg.max_keys += wcfg.max_keys / 4 + 1024;
-            wcfg.out_capacity = batch_len * world;
+            // a round carries up to one batch per local lane and rank: the lane batches hold up to 2 * n_sources / lanes input batches
+            wcfg.out_capacity = std::max<size_t>(2 * n_sources * batch_len / n_sinks_, batch_len);
         } else if (shared_keys) {
             // every lane carries every key: device KeyBy (one partition kernel chain per batch) in front of the replicas
             wcfg.lanes_are_key_disjoint = false;
@@ -402,6 +415,7 @@ public:
         d["overflow"] = overflow;
         d["skipped_windows"] = skipped;
         d["table_full"] = full;
+        if (exchange_) exchange_stats(d, exchange_->stats(), exchange_->getOutputLanes());
         return d;
     }
     void reset_latency() { latency_->clear(); }
@@ -727,13 +741,13 @@ public:
         punct_expected_ = n_sinks_ * n_sources;  // the device KeyBy copies a lane's punctuation to every replica
         if (transport) {
             exchange_ = ExchangeGPU_Builder<ysb::Joined>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
-                            .withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
+                            .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
             mp.add(*exchange_);
-            punct_expected_ = n_sinks_;  // the exchange merges the punctuations of a step into one
+            punct_expected_ = n_sinks_;  // the exchange merges the punctuations of a step into one per lane
         }
         agg_ = KeyFFATGPU_Builder(ysb::CountLift(), ysb::CountCombine()).withTBWindows(us(ysb::WINDOW_US), us(ysb::WINDOW_US), us(delay_us))
                    .withName("ysb_kff_gpu").withParallelism(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).withMaxKeys(256)
-                   .withOutputCapacity(8192).build_unique();
+                   .withOutputCapacity(8192).withKeyDisjointLanes(transport != nullptr).build_unique();
         mp.add(*agg_);
         auto sink_f = [totals, barrier](const ysb::WinResult* data, size_t n, const gpu::BatchHeader& h) {
             uint64_t res = 0, views = 0;
@@ -792,6 +806,7 @@ public:
         d["dropped"] = dropped;
         d["overflow"] = overflow;
         d["table_full"] = full;
+        if (exchange_) exchange_stats(d, exchange_->stats(), exchange_->getOutputLanes());
         return d;
     }
     void reset_latency() { latency_->clear(); }
@@ -843,22 +858,25 @@ static std::vector<uint64_t> transport_all_gather(dist::Transport& t, const std:
 }
 
 // Exchange_GPU conservation check: `world` in-process ranks (threads) on one device, each runs
-//   Batch_Source(n tuples, keys of its own) -> Exchange_GPU(LocalTransport) -> Batch_Sink
-// returns per rank {tuples received, value sum, tuples not owned by the rank, per-key order violations, rounds}
-static std::vector<std::vector<double>> exchange_local_run(int gpu_id, int world, size_t n_per_rank, size_t n_keys, size_t batch_len) {
+//   Batch_Source x n_sources (n tuples each, keys of their own) -> Exchange_GPU(LocalTransport, `lanes` output lanes) -> Batch_Sink x lanes
+// returns per rank {tuples received, value sum, tuples not owned by the (rank, lane) that saw them, per-key order violations,
+// rounds, input batches, batches delivered}
+static std::vector<std::vector<double>> exchange_local_run(int gpu_id, int world, size_t n_per_rank, size_t n_keys, size_t batch_len, size_t n_sources,
+                                                           size_t lanes, size_t max_batches_per_round) {
     py::gil_scoped_release rel;
     auto fabric = std::make_shared<dist::LocalFabric>(world);
-    std::vector<std::vector<double>> res((size_t)world, std::vector<double>(4, 0.0));
+    std::vector<std::vector<double>> res((size_t)world, std::vector<double>(7, 0.0));
     std::vector<std::thread> threads;
     for (int r = 0; r < world; r++) {
         threads.emplace_back([&, r] {
             auto tr = std::make_shared<dist::LocalTransport>(fabric, r);
             PipeGraph g("exchange_rank" + std::to_string(r), Mode::DEFAULT);
-            size_t sent = 0;
-            // rank r produces (r+1)/world of n_per_rank tuples: uneven streams exercise the end-of-stream rounds
-            const size_t n = n_per_rank * (size_t)(r + 1) / (size_t)world;
-            auto gen = [=](tuple_t& t) mutable {
-                t.key = (sent % n_keys) * (size_t)world + (size_t)r;  // keys of different ranks are disjoint
+            // rank r produces (r+1)/world of n_per_rank tuples per source: uneven streams exercise the end-of-stream rounds
+            const size_t n = std::max<size_t>(1, n_per_rank * (size_t)(r + 1) / (size_t)world);
+            const size_t S = n_sources;
+            auto gen = [=, sent = (size_t)0](tuple_t& t, RuntimeContext& rc) mutable {
+                // keys of different sources and ranks are disjoint: per-key order is the order of one producer
+                t.key = ((sent % n_keys) * S + rc.getReplicaIndex()) * (size_t)world + (size_t)r;
                 t.id = sent / n_keys;
                 t.ts = sent;
                 t.value = (double)(sent % 97);
@@ -866,26 +884,39 @@ static std::vector<std::vector<double>> exchange_local_run(int gpu_id, int world
                 sent++;
                 return sent < n;
             };
-            auto src = BatchSource_Builder(gen).withName("src").withParallelism(1).withBatch(batch_len).withGPUConfiguration(gpu_id).build_unique();
+            auto src = BatchSource_Builder(gen).withName("src").withParallelism(S).withBatch(batch_len).withGPUConfiguration(gpu_id).build_unique();
             MultiPipe& mp = g.add_source(*src);
-            auto ex = ExchangeGPU_Builder<tuple_t>(tr).withGPUConfiguration(gpu_id).build_unique();
+            auto ex = ExchangeGPU_Builder<tuple_t>(tr).withParallelism(S).withLocalLanes(S).withOutputLanes(lanes).withMaxBatchesPerRound(max_batches_per_round)
+                          .withGPUConfiguration(gpu_id).build_unique();
             mp.add(*ex);
-            std::map<uint64_t, uint64_t> last_id;
+            auto m = std::make_shared<std::mutex>();
             std::vector<double>* out = &res[(size_t)r];
-            const uint32_t W = (uint32_t)world;
-            auto sink_f = [out, W, r, last_id](const tuple_t* data, size_t cnt) mutable {
+            const uint32_t W = (uint32_t)world, L = (uint32_t)lanes;
+            auto sink_f = [out, m, W, L, r, last_id = std::map<uint64_t, uint64_t>()](const tuple_t* data, size_t cnt, RuntimeContext& rc) mutable {
+                double n_in = 0, sum = 0, foreign = 0, disorder = 0;
                 for (size_t i = 0; i < cnt; i++) {
-                    (*out)[0] += 1;
-                    (*out)[1] += data[i].value;
-                    if (gpu::keyby_destination(data[i].key, W, gpu::HASH_SHIFT_RANKS) != (uint32_t)r) (*out)[2] += 1;
+                    n_in += 1;
+                    sum += data[i].value;
+                    if (gpu::keyby_destination(data[i].key, W, gpu::HASH_SHIFT_RANKS) != (uint32_t)r ||
+                        gpu::keyby_destination(data[i].key, L, gpu::HASH_SHIFT_LANES) != (uint32_t)rc.getReplicaIndex())
+                        foreign += 1;
                     auto it = last_id.find(data[i].key);
-                    if (it != last_id.end() && data[i].id <= it->second) (*out)[3] += 1;
+                    if (it != last_id.end() && data[i].id <= it->second) disorder += 1;
                     last_id[data[i].key] = data[i].id;
                 }
+                std::lock_guard<std::mutex> l(*m);
+                (*out)[0] += n_in;
+                (*out)[1] += sum;
+                (*out)[2] += foreign;
+                (*out)[3] += disorder;
             };
-            auto sink = BatchSink_Builder(sink_f).withName("sink").withParallelism(1).build_unique();
+            auto sink = BatchSink_Builder(sink_f).withName("sink").withParallelism(lanes).build_unique();
             mp.add_sink(*sink);
             g.run();
+            const ExchangeStats x = ex->stats();
+            (*out)[4] = (double)x.rounds;
+            (*out)[5] = (double)x.bundles;
+            (*out)[6] = (double)x.lane_batches;
         });
     }
     for (auto& t : threads) t.join();
@@ -928,7 +959,7 @@ PYBIND11_MODULE(_C, m) {
         return std::make_shared<dist::LocalTransport>(std::move(f), rank);
     }, py::arg("fabric"), py::arg("rank"));
     m.def("exchange_local_run", &exchange_local_run, py::arg("gpu_id"), py::arg("world"), py::arg("n_per_rank"), py::arg("n_keys"),
-          py::arg("batch_len"));
+          py::arg("batch_len"), py::arg("n_sources") = 1, py::arg("lanes") = 1, py::arg("max_batches_per_round") = 0);
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
         .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t, int, double,
                       bool>(),

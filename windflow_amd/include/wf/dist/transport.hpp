@@ -7,23 +7,33 @@
 // nodes the GPUs are fully connected by point-to-point xGMI links, so the natural
 // scale-out of a keyed stream is: every rank ingests its own sources, tuples are
 // re-partitioned by key ACROSS ranks with one all-to-all per exchange round, and
-// the keyed state of a key lives on exactly one GPU.  This header is the thin
-// communication substrate of that design:
+// the keyed state of a key lives on exactly one GPU.  This header is the
+// communication substrate of that design, in two planes:
 //
-//   Transport        what the exchange operator needs (small host-visible
-//                    all-gather, device all-to-all-v, all-reduce, barrier)
-//   RcclTransport    ncclComm over xGMI; all-to-all-v = one grouped
-//                    ncclSend/ncclRecv per peer pair, so every link carries its
-//                    pair's slice concurrently (no ring: xGMI is point-to-point)
-//   LocalTransport   ranks are threads of one process sharing a LocalFabric;
-//                    used by the tests (several ranks on the one GPU of a test
-//                    box) and by single-process multi-GPU graphs
+//   control plane   ControlBoard: a small table in memory shared by the ranks (POSIX shared memory between the
+//                   processes of a node, plain heap between the threads of one process).  For every round each rank
+//                   publishes one row - the sizes of the slices it will send, end-of-stream and punctuation flags,
+//                   its watermark - and reads the others'.  Publishing and collecting are plain loads and stores:
+//                   no stream is synchronised and no collective runs to agree on the sizes of an all-to-all-v, so a
+//                   rank can publish several rounds ahead while earlier rounds are still moving data.
+//   data plane      Transport::exchange(): the all-to-all-v of one round, enqueued on a stream and never waited for
+//                   by the host.  RcclTransport: one grouped ncclSend/ncclRecv per peer pair, so every xGMI link
+//                   carries its pair's slice concurrently (no ring: the links are point to point).  LocalTransport:
+//                   ranks are threads of one process; a rank PULLS its slices from the peers' send buffers with
+//                   device copies (peer copies when the ranks sit on different GPUs) - the direct-store / load path
+//                   that needs no rendezvous at all.
 #pragma once
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <memory>
 #include <mutex>
@@ -37,6 +47,7 @@ namespace wf {
 namespace dist {
 
 constexpr int MAX_WORLD = 16;
+constexpr int MAX_LANES = 16;
 
 #define WF_RCCL_CHECK(expr)                                                                                         \
     do {                                                                                                            \
@@ -47,12 +58,96 @@ constexpr int MAX_WORLD = 16;
         }                                                                                                           \
     } while (0)
 
+// ---- control plane ---------------------------------------------------------------------------------
+// One row per (round, rank).  counts[d] = tuples this rank sends to destination d = owner_rank * lanes + lane.
+struct ControlRow {
+    uint32_t counts[MAX_WORLD * MAX_LANES];
+    uint64_t done;        // the rank's input stream has ended
+    uint64_t step;        // greatest step punctuation every local lane has delivered
+    uint64_t watermark;   // greatest timestamp of the rank's batch of this round
+    uint64_t created_ns;  // when the rank's batch of this round was opened (latency accounting)
+    uint64_t capacity;    // largest batch capacity the rank has seen (sizes the receive slabs)
+    uint64_t send_base;   // LocalTransport: address of the rank's send buffer for this round
+    uint64_t aux[2];
+};
+
+// Rounds are numbered 0, 1, 2...; the board keeps DEPTH of them.  A rank may publish round r once every rank has
+// collected round r - DEPTH (its slot is then free); tags make rows visible with release / acquire ordering.
+class ControlBoard {
+public:
+    static constexpr uint64_t DEPTH = 8;
+    struct Slot {
+        std::atomic<uint64_t> tag;  // round + 1 when the row is valid
+        ControlRow row;
+    };
+    struct Shared {
+        std::atomic<uint64_t> attached;                  // ranks that have mapped the board
+        std::atomic<uint64_t> collected[MAX_WORLD];      // rounds the rank has collected (next round to collect)
+        std::atomic<uint64_t> acked[DEPTH][MAX_WORLD];   // data plane: peers that are done with rank's send buffer of the round
+        std::atomic<uint64_t> barrier_count, barrier_gen;
+        Slot slots[DEPTH][MAX_WORLD];
+    };
+    static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control board needs lock-free 64-bit atomics");
+
+    ControlBoard(Shared* sh, int rank, int world) : sh_(sh), rank_(rank), world_(world) {}
+
+    bool can_publish(uint64_t round) const {
+        if (round < DEPTH) return true;
+        for (int r = 0; r < world_; r++)
+            if (sh_->collected[r].load(std::memory_order_acquire) + DEPTH <= round) return false;
+        return true;
+    }
+    // precondition: can_publish(round)
+    void publish(uint64_t round, const ControlRow& row) {
+        Slot& s = sh_->slots[round % DEPTH][rank_];
+        s.row = row;
+        sh_->acked[round % DEPTH][rank_].store(0, std::memory_order_relaxed);
+        s.tag.store(round + 1, std::memory_order_release);
+    }
+    bool published(uint64_t round, int rank) const { return sh_->slots[round % DEPTH][rank].tag.load(std::memory_order_acquire) == round + 1; }
+    // has any OTHER rank published this round?  (a rank without input answers such a round at once with an empty row)
+    bool anyone_published(uint64_t round) const {
+        for (int r = 0; r < world_; r++)
+            if (r != rank_ && published(round, r)) return true;
+        return false;
+    }
+    // all rows of the round, rank-major; false if some rank has not published yet
+    bool try_collect(uint64_t round, ControlRow* out) {
+        for (int r = 0; r < world_; r++)
+            if (!published(round, r)) return false;
+        for (int r = 0; r < world_; r++) out[r] = sh_->slots[round % DEPTH][r].row;
+        sh_->collected[rank_].store(round + 1, std::memory_order_release);
+        return true;
+    }
+    // data plane acknowledgements (pull transports): `rank`'s send buffer of `round` has been copied by one more peer
+    void ack(uint64_t round, int rank) { sh_->acked[round % DEPTH][rank].fetch_add(1, std::memory_order_acq_rel); }
+    uint64_t acks(uint64_t round) const { return sh_->acked[round % DEPTH][rank_].load(std::memory_order_acquire); }
+    // host barrier over the ranks (setup / teardown only)
+    void barrier() {
+        const uint64_t gen = sh_->barrier_gen.load(std::memory_order_acquire);
+        if (sh_->barrier_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)world_) {
+            sh_->barrier_count.store(0, std::memory_order_relaxed);
+            sh_->barrier_gen.store(gen + 1, std::memory_order_release);
+        } else {
+            while (sh_->barrier_gen.load(std::memory_order_acquire) == gen) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+
+private:
+    Shared* sh_;
+    int rank_, world_;
+};
+
 // per-peer slices of one all-to-all-v (device pointers, byte counts)
 struct PeerSlices {
     const void* send[MAX_WORLD] = {};
     size_t send_bytes[MAX_WORLD] = {};
     void* recv[MAX_WORLD] = {};
     size_t recv_bytes[MAX_WORLD] = {};
+    // pull transports: where my slice starts inside peer p's send buffer (bytes from the peer's ControlRow::send_base)
+    size_t pull_offset[MAX_WORLD] = {};
 };
 
 class Transport {
@@ -61,18 +156,25 @@ public:
     int rank() const { return rank_; }
     int world() const { return world_; }
     virtual const char* name() const = 0;
-    // every rank contributes `words` 64-bit words; on return `out` (host memory,
-    // world*words words, rank-major) holds everybody's contribution.  Ordered
-    // after the work already enqueued on `s`.
-    virtual void all_gather_host(const uint64_t* mine, uint64_t* out, size_t words, hipStream_t s) = 0;
-    // device all-to-all with per-peer sizes, enqueued on `s` (returns without waiting)
-    virtual void all_to_all_v(const PeerSlices& p, hipStream_t s) = 0;
+    ControlBoard& board() { return *board_; }
+    // all-to-all-v of round `round`, enqueued on `s` (returns without waiting).  `rows` are the collected rows of the round.
+    virtual void exchange(uint64_t round, const PeerSlices& p, const ControlRow* rows, hipStream_t s) = 0;
+    // true: peers read this rank's send buffer on their own streams, from the moment the round's row is on the board -
+    // a row must not be published before the buffer is complete
+    virtual bool pulls() const { return false; }
+    // may the send buffers handed to exchange(round) be reused?  (non-blocking)
+    virtual bool sends_done(uint64_t round) = 0;
+    // end of stream: complete (and acknowledge) every transfer this rank still has in flight on `s`
+    virtual void quiesce(hipStream_t) {}
     // element-wise sum of `n` doubles in device memory, in place, enqueued on `s`
     virtual void all_reduce_sum(double* dev, size_t n, hipStream_t s) = 0;
-    virtual void barrier(hipStream_t s) = 0;
+    // every rank contributes `words` 64-bit words (small, setup-time data); blocking
+    virtual void all_gather_host(const uint64_t* mine, uint64_t* out, size_t words, hipStream_t s) = 0;
+    virtual void barrier(hipStream_t) { board_->barrier(); }
 
 protected:
     int rank_ = 0, world_ = 1;
+    std::unique_ptr<ControlBoard> board_;
 };
 
 // ---- RCCL -------------------------------------------------------------------------
@@ -97,11 +199,51 @@ public:
         WF_RCCL_CHECK(ncclCommInitRank(&comm_, world, id, rank));
         stage_dev_.resize(STAGE_WORDS * (size_t)(world + 1));
         stage_host_.resize(STAGE_WORDS * (size_t)(world + 1));
+        // the control board lives in POSIX shared memory named after the unique id (every rank of the job derives the
+        // same name; a fresh segment is zero-filled, which is the board's initial state)
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char c : id_bytes) h = (h ^ c) * 1099511628211ull;
+        shm_name_ = "/wf_board_" + std::to_string(h);
+        const int fd = shm_open(shm_name_.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) gpu::failwith("RcclTransport: shm_open failed for the control board");
+        if (ftruncate(fd, (off_t)sizeof(ControlBoard::Shared)) != 0) gpu::failwith("RcclTransport: ftruncate failed for the control board");
+        void* p = mmap(nullptr, sizeof(ControlBoard::Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) gpu::failwith("RcclTransport: mmap failed for the control board");
+        shared_ = static_cast<ControlBoard::Shared*>(p);
+        board_.reset(new ControlBoard(shared_, rank, world));
+        // nobody uses the board before everybody has mapped it; then the name can go (the mapping stays)
+        shared_->attached.fetch_add(1, std::memory_order_acq_rel);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        while (shared_->attached.load(std::memory_order_acquire) < (uint64_t)world) {
+            if (std::chrono::steady_clock::now() > deadline) gpu::failwith("RcclTransport: timed out waiting for the other ranks to map the control board");
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        board_->barrier();
+        if (rank == 0) shm_unlink(shm_name_.c_str());
+        for (auto& e : round_events_) e.reset(new gpu::Event());
     }
     ~RcclTransport() override {
         if (comm_) (void)ncclCommDestroy(comm_);
+        if (shared_) munmap(shared_, sizeof(ControlBoard::Shared));
     }
     const char* name() const override { return "rccl"; }
+
+    void exchange(uint64_t round, const PeerSlices& p, const ControlRow*, hipStream_t s) override {
+        std::lock_guard<std::mutex> l(m_);
+        bool any = false;
+        for (int peer = 0; peer < world_; peer++) any = any || p.send_bytes[peer] > 0 || p.recv_bytes[peer] > 0;
+        if (any) {
+            WF_RCCL_CHECK(ncclGroupStart());
+            for (int peer = 0; peer < world_; peer++) {
+                if (p.send_bytes[peer] > 0) WF_RCCL_CHECK(ncclSend(p.send[peer], p.send_bytes[peer], ncclChar, peer, comm_, s));
+                if (p.recv_bytes[peer] > 0) WF_RCCL_CHECK(ncclRecv(p.recv[peer], p.recv_bytes[peer], ncclChar, peer, comm_, s));
+            }
+            WF_RCCL_CHECK(ncclGroupEnd());
+        }
+        round_events_[round % ControlBoard::DEPTH]->record(s);
+    }
+    bool sends_done(uint64_t round) override { return round_events_[round % ControlBoard::DEPTH]->done(); }
 
     void all_gather_host(const uint64_t* mine, uint64_t* out, size_t words, hipStream_t s) override {
         if (words > STAGE_WORDS) gpu::failwith("RcclTransport::all_gather_host: too many words");
@@ -118,24 +260,9 @@ public:
         std::memcpy(out, h_recv, words * sizeof(uint64_t) * (size_t)world_);
     }
 
-    void all_to_all_v(const PeerSlices& p, hipStream_t s) override {
-        std::lock_guard<std::mutex> l(m_);
-        WF_RCCL_CHECK(ncclGroupStart());
-        for (int peer = 0; peer < world_; peer++) {
-            if (p.send_bytes[peer] > 0) WF_RCCL_CHECK(ncclSend(p.send[peer], p.send_bytes[peer], ncclChar, peer, comm_, s));
-            if (p.recv_bytes[peer] > 0) WF_RCCL_CHECK(ncclRecv(p.recv[peer], p.recv_bytes[peer], ncclChar, peer, comm_, s));
-        }
-        WF_RCCL_CHECK(ncclGroupEnd());
-    }
-
     void all_reduce_sum(double* dev, size_t n, hipStream_t s) override {
         std::lock_guard<std::mutex> l(m_);
         WF_RCCL_CHECK(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, s));
-    }
-
-    void barrier(hipStream_t s) override {
-        uint64_t x = 1, out[MAX_WORLD];
-        all_gather_host(&x, out, 1, s);
     }
 
 private:
@@ -145,6 +272,9 @@ private:
     std::mutex m_;  // one collective at a time per communicator
     gpu::DeviceBuffer<uint64_t> stage_dev_;
     gpu::PinnedBuffer<uint64_t> stage_host_;
+    std::string shm_name_;
+    ControlBoard::Shared* shared_ = nullptr;
+    std::unique_ptr<gpu::Event> round_events_[ControlBoard::DEPTH];
 };
 
 // rank 0 writes the id to `path` (atomically), the others poll for it: bootstrap for
@@ -173,10 +303,10 @@ inline std::string bootstrap_id_via_file(const std::string& path, int rank, int 
 }
 
 // ---- in-process fabric ---------------------------------------------------------------
-// Shared by the `world` LocalTransports of one process.
+// Shared by the `world` LocalTransports of one process: the control board in plain memory + scratch for the blocking helpers.
 class LocalFabric {
 public:
-    explicit LocalFabric(int world) : world_(world), gather_((size_t)world * 64), slices_(world), reduce_(world) {
+    explicit LocalFabric(int world) : world_(world), shared_(new ControlBoard::Shared()), gather_((size_t)world * 64), reduce_(world) {
         if (world < 1 || world > MAX_WORLD) gpu::failwith("LocalFabric: world size out of range");
     }
     int world() const { return world_; }
@@ -196,22 +326,53 @@ public:
 private:
     friend class LocalTransport;
     int world_;
+    std::unique_ptr<ControlBoard::Shared> shared_;  // value-initialised: all tags and counters zero
     std::mutex m_;
     std::condition_variable cv_;
     int arrived_ = 0;
     uint64_t gen_ = 0;
     std::vector<uint64_t> gather_;
-    std::vector<PeerSlices> slices_;
     std::vector<std::pair<double*, size_t>> reduce_;
 };
 
+// A rank PULLS: the peers' rows carry the addresses of their send buffers, so the receiver copies its slices out of them
+// with device copies on its own stream - no rendezvous, the sender only learns (through the board) when everybody is done
+// with its buffer.  Between GPUs of one process these are peer copies over xGMI.
 class LocalTransport : public Transport {
 public:
     LocalTransport(std::shared_ptr<LocalFabric> fabric, int rank) : fabric_(std::move(fabric)) {
         rank_ = rank;
         world_ = fabric_->world();
+        board_.reset(new ControlBoard(fabric_->shared_.get(), rank, world_));
     }
     const char* name() const override { return "local"; }
+    bool pulls() const override { return true; }
+
+    void exchange(uint64_t round, const PeerSlices& p, const ControlRow* rows, hipStream_t s) override {
+        bool copied = false;
+        for (int peer = 0; peer < world_; peer++) {
+            if (p.recv_bytes[peer] == 0) continue;
+            const char* src = reinterpret_cast<const char*>((uintptr_t)rows[peer].send_base) + p.pull_offset[peer];
+            WF_HIP_CHECK(hipMemcpyAsync(p.recv[peer], src, p.recv_bytes[peer], hipMemcpyDefault, s));
+            copied = true;
+        }
+        if (!copied) {  // nothing to wait for: the peers' buffers are free as far as this rank is concerned
+            for (int peer = 0; peer < world_; peer++) board_->ack(round, peer);
+            return;
+        }
+        std::unique_ptr<gpu::Event> e(new gpu::Event());
+        e->record(s);
+        pending_.push_back({round, std::move(e)});
+        poll_acks();
+    }
+    bool sends_done(uint64_t round) override {
+        poll_acks();
+        return board_->acks(round) >= (uint64_t)world_;
+    }
+    void quiesce(hipStream_t s) override {
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+        poll_acks();
+    }
 
     void all_gather_host(const uint64_t* mine, uint64_t* out, size_t words, hipStream_t) override {
         if (words > 64) gpu::failwith("LocalTransport::all_gather_host: too many words");
@@ -219,19 +380,6 @@ public:
         fabric_->sync();
         for (int r = 0; r < world_; r++) std::memcpy(out + (size_t)r * words, &fabric_->gather_[(size_t)r * 64], words * sizeof(uint64_t));
         fabric_->sync();
-    }
-
-    void all_to_all_v(const PeerSlices& p, hipStream_t s) override {
-        WF_HIP_CHECK(hipStreamSynchronize(s));  // my slices are complete before anybody reads them
-        fabric_->slices_[rank_] = p;
-        fabric_->sync();
-        for (int peer = 0; peer < world_; peer++) {
-            const PeerSlices& q = fabric_->slices_[peer];
-            if (q.send_bytes[rank_] != p.recv_bytes[peer]) gpu::failwith("LocalTransport::all_to_all_v: size mismatch between ranks");
-            if (p.recv_bytes[peer] > 0) WF_HIP_CHECK(hipMemcpyAsync(p.recv[peer], q.send[rank_], p.recv_bytes[peer], hipMemcpyDefault, s));
-        }
-        WF_HIP_CHECK(hipStreamSynchronize(s));
-        fabric_->sync();  // senders may now reuse their buffers
     }
 
     void all_reduce_sum(double* dev, size_t n, hipStream_t s) override {
@@ -253,7 +401,15 @@ public:
     void barrier(hipStream_t) override { fabric_->sync(); }
 
 private:
+    // my copies of a round have completed: tell every peer its send buffer of that round is free (for me)
+    void poll_acks() {
+        while (!pending_.empty() && pending_.front().second->done()) {
+            for (int peer = 0; peer < world_; peer++) board_->ack(pending_.front().first, peer);
+            pending_.pop_front();
+        }
+    }
     std::shared_ptr<LocalFabric> fabric_;
+    std::deque<std::pair<uint64_t, std::unique_ptr<gpu::Event>>> pending_;
 };
 
 }  // namespace dist

@@ -18,6 +18,7 @@ namespace wf {
 namespace gpu {
 
 constexpr int MAX_PARTITIONS = 16;
+constexpr int MAX_PACKED_PARTITIONS = 256;  // packed form (one output slab): destinations = ranks x lanes
 constexpr uint32_t HASH_SHIFT_LANES = 24;
 constexpr uint32_t HASH_SHIFT_RANKS = 48;
 
@@ -33,7 +34,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     partition_offsets_kernel(const BatchHeader* hdr, const uint32_t* sorted_dest, uint32_t n_dest, uint32_t* offsets) {
     const uint32_t n = hdr->count;
     if (n == 0) {
-        if (blockIdx.x == 0 && threadIdx.x <= n_dest) offsets[threadIdx.x] = 0;
+        if (blockIdx.x == 0)
+            for (uint32_t x = threadIdx.x; x <= n_dest; x += blockDim.x) offsets[x] = 0;
         return;
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -60,6 +62,35 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t d = sorted_dest[i];
         tab.data[d][i - offsets[d]] = in[perm[i]];
     }
+}
+
+// two-level destination of the cross-GPU exchange: owner rank from bits 48-63 of the key hash, lane inside the rank from
+// bits 24-47 (the device key tables use the low bits): dest = rank * n_lanes + lane
+template <typename T, typename KeyFn>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    dest_keys2_kernel(const BatchHeader* hdr, const T* data, uint32_t n_ranks, uint32_t n_lanes, uint32_t* dest, uint32_t* idx, KeyFn keyfn) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t h = mix64((uint64_t)keyfn(data[i]));
+        const uint32_t rank = (uint32_t)(((h >> HASH_SHIFT_RANKS) & 0xffffull) % n_ranks);
+        const uint32_t lane = (uint32_t)(((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes);
+        dest[i] = rank * n_lanes + lane;
+        idx[i] = i;
+    }
+}
+
+// packed form of the scatter: ONE output slab holding the tuples grouped by destination (stable), plus the n_dest + 1
+// segment offsets mirrored into pinned memory - the send buffer and the send counts of an all-to-all-v
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    partition_pack_kernel(const BatchHeader* in_hdr, const T* in, const uint32_t* perm, const uint32_t* offsets, BatchHeader* out_hdr, T* out,
+                          volatile uint32_t* offsets_mirror, uint32_t n_dest) {
+    const uint32_t n = in_hdr->count;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *out_hdr = *in_hdr;
+        for (uint32_t d = threadIdx.x; d <= n_dest; d += blockDim.x) offsets_mirror[d] = offsets[d];
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[perm[i]];
 }
 
 // Partitions device batches of T into n_dest device batches (stable within a destination).
@@ -106,6 +137,38 @@ public:
         hipLaunchKernelGGL((partition_scatter_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                            sorted.keys, sorted.vals, offsets_.data(), tab, (uint32_t)n_dest_);
         kernels += 3 + sorter_.kernels_per_sort(bits_);
+    }
+    // Packed form for the cross-GPU exchange: destinations are (rank, lane) pairs, the output is one slab ordered by
+    // destination; mirror_for(slab) names the pinned array (n_ranks * n_lanes + 1 words) that receives the segment offsets
+    // of that slab.
+    template <typename MirrorFn>
+    Batch* partition_packed(Batch* in, size_t n_ranks, size_t n_lanes, MirrorFn mirror_for, hipStream_t s, uint64_t& kernels) {
+        const size_t D = n_ranks * n_lanes;
+        if (D == 0 || D > (size_t)MAX_PACKED_PARTITIONS) failwith("BatchPartitioner: unsupported number of (rank, lane) destinations");
+        const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
+        if (pool_ && upper > pool_->capacity()) failwith("BatchPartitioner: a batch larger than the first one received");
+        if (!pool_) {
+            pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(T), in->capacity, pool_slabs_));
+            dest_.resize(in->capacity);
+            idx_.resize(in->capacity);
+            offsets_.resize(MAX_PACKED_PARTITIONS + 1);
+            sorter_.reserve(in->capacity);
+        }
+        int bits = 1;
+        while ((1u << bits) < D) bits++;
+        Batch* o = pool_->acquire(s);
+        o->host_hdr = in->host_hdr;
+        o->count_on_host = in->count_on_host;
+        volatile uint32_t* offsets_mirror = mirror_for(o);
+        const unsigned grid = grid_for(std::max<size_t>(upper, 1));
+        hipLaunchKernelGGL((dest_keys2_kernel<T, KeyOfAny>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), (uint32_t)n_ranks,
+                           (uint32_t)n_lanes, dest_.data(), idx_.data(), KeyOfAny{});
+        const auto sorted = sorter_.sort(dest_.data(), idx_.data(), in->device_count_ptr(), std::max<size_t>(upper, 1), bits, s);
+        hipLaunchKernelGGL(partition_offsets_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), sorted.keys, (uint32_t)D, offsets_.data());
+        hipLaunchKernelGGL((partition_pack_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.vals,
+                           offsets_.data(), o->header(), o->template data<T>(), offsets_mirror, (uint32_t)D);
+        kernels += 3 + sorter_.kernels_per_sort(bits);
+        return o;
     }
     size_t n_dest() const { return n_dest_; }
 
