@@ -16,6 +16,11 @@ namespace ysb {
 struct ViewFilterGPU {
     __host__ __device__ bool operator()(const Event& e) const { return e.event_type == 0; }
 };
+// split/merge variant of the query: the events are split by ad type into two branches (each filters and joins its share)
+// that are merged again in front of the aggregation
+struct AdTypeSplit {
+    __host__ __device__ size_t operator()(const Event& e) const { return e.ad_type & 1u; }
+};
 // stream-table join without a table: ad ids are a fixed permutation of [0, n_ads) (ysb::Campaigns), inverted arithmetically
 struct JoinGPU {
     uint64_t n_ads, per_campaign, inv_a, b;

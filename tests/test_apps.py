@@ -20,14 +20,14 @@ def ext():
     return windflow_amd.load_ext()
 
 
-def run_app(name, args, hip=False, timeout=110):
+def run_app(name, args, hip=False, timeout=110, extra=()):
     src = os.path.join(ROOT, "apps", "ysb", name + (".hip" if hip else ".cpp"))
-    exe = wfbuild.build_cpp(src, os.path.join(ROOT, "apps", "bin", name), hip=hip, extra=["-I" + os.path.dirname(src)])
+    exe = wfbuild.build_cpp(src, os.path.join(ROOT, "apps", "bin", name), hip=hip, extra=["-I" + os.path.dirname(src), *extra])
     r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = {}
     for key in ("generated events", "received results", "events counted in windows"):
-        out[key] = int(re.search(key + r" (\d+)", r.stdout).group(1))
+        out[key] = int(re.search(r"\[" + name + r"\] " + key + r" (\d+)", r.stdout).group(1))
     return out
 
 
@@ -53,11 +53,12 @@ def test_ysb_gpu(n, m, batch, engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sources,replicas", [(2, 1), (3, 2)])
-def test_ysb_pipeline_steps(ext, sources, replicas):
-    """the pipeline bench.py drives: gated steps, closed-form oracle"""
+@pytest.mark.parametrize("sources,replicas,split_merge", [(2, 1, False), (3, 2, False), (2, 2, True), (3, 1, True)])
+def test_ysb_pipeline_steps(ext, sources, replicas, split_merge):
+    """the pipeline bench.py drives: gated steps, closed-form oracle.  split_merge: the events are split on the device by
+    ad type into two filter+join branches that are merged again (device batches all the way)"""
     per_source, period = 1_200_000, 10
-    pipe = ext.YsbPipeline(0, sources, 16384, period, 30_000_000, 4, replicas)
+    pipe = ext.YsbPipeline(0, sources, 16384, period, 30_000_000, 4, replicas, None, split_merge)
     pipe.step(per_source)
     pipe.step(per_source)
     pipe.close()
@@ -66,3 +67,23 @@ def test_ysb_pipeline_steps(ext, sources, replicas):
     assert st["counted_views"] == exp["events counted in windows"]
     assert st["sink_tuples"] == exp["received results"]
     assert st["dropped"] == 0 and st["overflow"] == 0 and st["table_full"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,n,m,split", [(1, 2, 2, 0), (2, 2, 1, 0), (3, 1, 2, 1)])
+def test_ysb_gpu_dist_local_ranks(ranks, n, m, split):
+    """the distributed application with its ranks as threads of one process (LocalTransport): campaigns partitioned across
+    ranks by Exchange_GPU, totals of the job against the closed form"""
+    got = run_app("ysb_gpu_dist", ["-e", 2_500_000, "-p", 10, "-n", n, "-m", m, "-b", 8192, "-d", 30_000_000, "-x", split, "-t", "local", "-r", ranks],
+                  hip=True, extra=wfbuild.RCCL_FLAGS)
+    exp = expected(2_500_000, n * ranks)
+    exp["received results"] = expected(2_500_000, 1)["received results"]  # a (campaign, window) pair exists once in the job
+    assert got == exp
+
+
+@pytest.mark.gpu
+def test_ysb_gpu_dist_rccl_single_rank():
+    """one process, RCCL transport with world size 1 (the id travels through the bootstrap file)"""
+    got = run_app("ysb_gpu_dist", ["-e", 1_000_000, "-p", 10, "-n", 2, "-m", 2, "-b", 8192, "-d", 30_000_000, "-t", "rccl", "-i", "/tmp/wf_test_rccl_id"],
+                  hip=True, extra=wfbuild.RCCL_FLAGS)
+    assert got == expected(1_000_000, 2)

@@ -80,7 +80,9 @@ def build_cpp(src, out, hip=False, extra=()):
 
 REPO = os.path.dirname(ROOT)
 
-# (source, binary, hip?) of every native program in the tree: regression programs and applications
+RCCL_FLAGS = ["-I/opt/rocm/include/rccl", "-L/opt/rocm/lib", "-lrccl"]
+
+# (source, binary, hip?[, extra flags]) of every native program in the tree: regression programs and applications
 PROGRAMS = [
     ("tests/cpp/smoke_basic_ops.cpp", "tests/cpp/bin/smoke_basic_ops", False),
     ("tests/cpp/test_mp_windows.cpp", "tests/cpp/bin/test_mp_windows", False),
@@ -92,6 +94,7 @@ PROGRAMS = [
     ("apps/ysb/ysb_kf.cpp", "apps/bin/ysb_kf", False),
     ("apps/ysb/ysb_wmr.cpp", "apps/bin/ysb_wmr", False),
     ("apps/ysb/ysb_gpu.hip", "apps/bin/ysb_gpu", True),
+    ("apps/ysb/ysb_gpu_dist.hip", "apps/bin/ysb_gpu_dist", True, RCCL_FLAGS),
     ("apps/bench/bench_ops_gpu.hip", "apps/bin/bench_ops_gpu", True),
     ("apps/bench/bench_win_gpu.hip", "apps/bin/bench_win_gpu", True),
     ("apps/bench/probe/hip_leak_probe.hip", "apps/bin/hip_leak_probe", True),
@@ -108,13 +111,13 @@ def build_programs(verbose=True, jobs=None):
     jobs = jobs or int(os.environ.get("MAX_JOBS", "0")) or min(6, os.cpu_count() or 1)
 
     def one(prog):
-        src, out, hip = prog
+        src, out, hip = prog[:3]
         s, o = os.path.join(REPO, src), os.path.join(REPO, out)
         if not os.path.exists(s):
             return None
         if verbose:
             print("[windflow_amd.build] program", src, flush=True)
-        return build_cpp(s, o, hip=hip, extra=["-I" + os.path.dirname(s)])
+        return build_cpp(s, o, hip=hip, extra=["-I" + os.path.dirname(s)] + list(prog[3] if len(prog) > 3 else []))
 
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         return [b for b in pool.map(one, PROGRAMS) if b]

@@ -722,8 +722,10 @@ struct YsbTotals {
 
 class YsbPipeline {
 public:
+    // split_merge: the events are split on the device by ad type into two branches, each with its own Filter_GPU -> Map_GPU(join),
+    // and the branches are merged again in front of the exchange / aggregation (BASELINE.json config 5)
     YsbPipeline(int gpu_id, size_t n_sources, size_t batch_len, uint64_t period_us, uint64_t delay_us, size_t inflight, size_t agg_replicas,
-                std::shared_ptr<dist::Transport> transport = nullptr)
+                std::shared_ptr<dist::Transport> transport = nullptr, bool split_merge = false)
         : n_sources_(n_sources), n_sinks_(agg_replicas ? agg_replicas : 1), gates_(new wfbench::StepGate[n_sources]),
           graph_("ysb_gpu", Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<YsbTotals>();
@@ -731,24 +733,42 @@ public:
         const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
         source_ = BatchSource_Builder(GatedEventSource(gates_.get(), &campaigns_, period_us)).withName("ysb_source").withParallelism(n_sources)
                       .withBatch(batch_len).withInFlightBatches(inflight).withGPUConfiguration(gpu_id).build_unique();
-        MultiPipe& mp = graph_.add_source(*source_);
-        filter_ = FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
-                      .withGPUConfiguration(gpu_id).build_unique();
-        mp.add(*filter_);
-        join_ = MapGPU_Builder(ysb::JoinGPU(campaigns_)).withName("ysb_join_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
-                    .withGPUConfiguration(gpu_id).build_unique();
-        mp.chain(*join_);
-        punct_expected_ = n_sinks_ * n_sources;  // the device KeyBy copies a lane's punctuation to every replica
+        MultiPipe* mp = &graph_.add_source(*source_);
+        const size_t branches = split_merge ? 2 : 1;
+        for (size_t b = 0; b < branches; b++) {
+            filter_.push_back(FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                                  .withGPUConfiguration(gpu_id).build_unique());
+            join_.push_back(MapGPU_Builder(ysb::JoinGPU(campaigns_)).withName("ysb_join_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+                                .withGPUConfiguration(gpu_id).build_unique());
+        }
+        if (split_merge) {
+            GPUConfig scfg;
+            scfg.gpu_id = gpu_id;
+            scfg.pool_slabs = inflight;
+            split_gpu(*mp, ysb::AdTypeSplit(), 2, scfg);
+            MultiPipe& b0 = mp->select(0);
+            b0.add(*filter_[0]);
+            b0.chain(*join_[0]);
+            MultiPipe& b1 = mp->select(1);
+            b1.add(*filter_[1]);
+            b1.chain(*join_[1]);
+            mp = &b0.merge(b1);
+        } else {
+            mp->add(*filter_[0]);
+            mp->chain(*join_[0]);
+        }
+        // a lane's step punctuation reaches the aggregation once per branch; the device KeyBy copies it to every replica
+        punct_expected_ = n_sinks_ * n_sources * branches;
         if (transport) {
-            exchange_ = ExchangeGPU_Builder<ysb::Joined>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
+            exchange_ = ExchangeGPU_Builder<ysb::Joined>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources * branches)
                             .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
-            mp.add(*exchange_);
+            mp->add(*exchange_);
             punct_expected_ = n_sinks_;  // the exchange merges the punctuations of a step into one per lane
         }
         agg_ = KeyFFATGPU_Builder(ysb::CountLift(), ysb::CountCombine()).withTBWindows(us(ysb::WINDOW_US), us(ysb::WINDOW_US), us(delay_us))
                    .withName("ysb_kff_gpu").withParallelism(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).withMaxKeys(256)
                    .withOutputCapacity(8192).withKeyDisjointLanes(transport != nullptr).build_unique();
-        mp.add(*agg_);
+        mp->add(*agg_);
         auto sink_f = [totals, barrier](const ysb::WinResult* data, size_t n, const gpu::BatchHeader& h) {
             uint64_t res = 0, views = 0;
             for (size_t i = 0; i < n; i++) {
@@ -765,7 +785,7 @@ public:
             if (h.reserved[0] != 0) barrier->arrive(h.reserved[0]);
         };
         sink_ = BatchSink_Builder(sink_f).withName("ysb_sink").withParallelism(n_sinks_).build_unique();
-        mp.chain_sink(*sink_);
+        mp->chain_sink(*sink_);
         latency_ = sink_->latency();
         graph_.start();
     }
@@ -821,8 +841,8 @@ private:
     std::shared_ptr<wfbench::StepBarrier> barrier_;
     std::shared_ptr<LatencyRecorder> latency_;
     std::unique_ptr<Batch_Source<ysb::Event>> source_;
-    std::unique_ptr<Filter_GPU<ysb::Event>> filter_;
-    std::unique_ptr<Map_GPU<ysb::Event, ysb::Joined>> join_;
+    std::vector<std::unique_ptr<Filter_GPU<ysb::Event>>> filter_;
+    std::vector<std::unique_ptr<Map_GPU<ysb::Event, ysb::Joined>>> join_;
     std::unique_ptr<Exchange_GPU<ysb::Joined>> exchange_;
     std::unique_ptr<Key_FFAT_GPU<ysb::Joined, ysb::WinResult>> agg_;
     std::unique_ptr<Batch_Sink<ysb::WinResult>> sink_;
@@ -987,9 +1007,9 @@ PYBIND11_MODULE(_C, m) {
         .def("reset_latency", &WinSeqPipeline::reset_latency)
         .def("dot", &WinSeqPipeline::dot);
     py::class_<YsbPipeline>(m, "YsbPipeline")
-        .def(py::init<int, size_t, size_t, uint64_t, uint64_t, size_t, size_t, std::shared_ptr<dist::Transport>>(), py::arg("gpu_id"),
+        .def(py::init<int, size_t, size_t, uint64_t, uint64_t, size_t, size_t, std::shared_ptr<dist::Transport>, bool>(), py::arg("gpu_id"),
              py::arg("n_sources"), py::arg("batch_len"), py::arg("period_us") = 1, py::arg("delay_us") = 1000000, py::arg("inflight") = 4,
-             py::arg("agg_replicas") = 1, py::arg("transport") = nullptr)
+             py::arg("agg_replicas") = 1, py::arg("transport") = nullptr, py::arg("split_merge") = false)
         .def("step", &YsbPipeline::step)
         .def("steps", &YsbPipeline::steps)
         .def("close", &YsbPipeline::close)

@@ -11,6 +11,7 @@
 // and carry their counts in device headers + pinned mirrors, so neither a GPU
 // consumer nor the RCCL exchange (dist/exchange.hpp) needs the host to size them.
 #pragma once
+#include "../pipegraph.hpp"
 #include "batch_ops.hpp"
 #include "primitives.hpp"
 
@@ -79,6 +80,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// destination from a user functor (device split: MultiPipe::split_gpu)
+template <typename T, typename DestFn>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    dest_fn_kernel(const BatchHeader* hdr, const T* data, uint32_t n_dest, uint32_t* dest, uint32_t* idx, DestFn fn) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        dest[i] = (uint32_t)((uint64_t)fn(data[i]) % n_dest);
+        idx[i] = i;
+    }
+}
+
 // packed form of the scatter: ONE output slab holding the tuples grouped by destination (stable), plus the n_dest + 1
 // segment offsets mirrored into pinned memory - the send buffer and the send counts of an all-to-all-v
 template <typename T>
@@ -107,7 +119,10 @@ public:
         while ((1u << bits_) < n_dest_) bits_++;
     }
     // enqueue on `s`; `outs` receives n_dest batches whose counts live on the device (+ pinned mirrors)
-    void partition(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels) {
+    void partition(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels) { partition_with(in, s, outs, kernels, HashDest{hash_shift_}); }
+    // the same with the destination chosen by `fn(tuple)` modulo n_dest (any functor callable on the device)
+    template <typename DestFn>
+    void partition_with(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels, DestFn fn) {
         const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
         if (pool_ && upper > pool_->capacity()) failwith("BatchPartitioner: a batch larger than the first one received");
         if (!pool_) {
@@ -129,8 +144,8 @@ public:
             outs.push_back(o);
         }
         const unsigned grid = grid_for(std::max<size_t>(upper, 1));
-        hipLaunchKernelGGL((dest_keys_kernel<T, KeyOfAny>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                           (uint32_t)n_dest_, dest_.data(), idx_.data(), KeyOfAny{}, hash_shift_);
+        hipLaunchKernelGGL((dest_fn_kernel<T, DestFn>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                           (uint32_t)n_dest_, dest_.data(), idx_.data(), fn);
         const auto sorted = sorter_.sort(dest_.data(), idx_.data(), in->device_count_ptr(), std::max<size_t>(upper, 1), bits_, s);
         hipLaunchKernelGGL(partition_offsets_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), sorted.keys, (uint32_t)n_dest_,
                            offsets_.data());
@@ -176,6 +191,13 @@ private:
     struct KeyOfAny {
         __host__ __device__ uint64_t operator()(const T& t) const { return (uint64_t)std::get<0>(t.getControlFields()); }
     };
+    // KeyBy: 24 bits of the key hash picked by hash_shift
+    struct HashDest {
+        uint32_t shift;
+        __host__ __device__ uint64_t operator()(const T& t) const {
+            return (mix64((uint64_t)std::get<0>(t.getControlFields())) >> shift) & 0xffffffull;
+        }
+    };
     size_t n_dest_;
     int device_;
     size_t pool_slabs_;
@@ -193,13 +215,17 @@ __host__ __device__ inline uint32_t keyby_destination(uint64_t key, uint32_t n_d
 
 }  // namespace gpu
 
-// Emitter node fused on a producer of batches: ships host batches to the device if
-// needed, partitions by key and sends sub-batch d to destination d.
-template <typename T>
-class KeyBy_EmitterGPU : public rt::Node {
+// Emitter node fused on a producer of batches: ships host batches to the device if needed, partitions them on the
+// device and sends sub-batch d to destination d.  DestFn = void: by key hash (KeyBy); otherwise by `fn(tuple) % n_dest`
+// (the device form of MultiPipe::split).
+template <typename T, typename DestFn = void>
+class Partition_EmitterGPU : public rt::Node {
+    struct NoFn {};
+    using fn_t = std::conditional_t<std::is_void_v<DestFn>, NoFn, DestFn>;
+
 public:
-    KeyBy_EmitterGPU(size_t n_dest, edge_kind_t in_kind, int device, size_t pool_slabs)
-        : n_dest_(n_dest), in_kind_(in_kind), device_(device), slabs_(pool_slabs), part_(n_dest, device, pool_slabs) {
+    Partition_EmitterGPU(size_t n_dest, edge_kind_t in_kind, int device, size_t pool_slabs, fn_t fn = fn_t{})
+        : n_dest_(n_dest), in_kind_(in_kind), device_(device), slabs_(pool_slabs), part_(n_dest, device, pool_slabs), fn_(fn) {
         for (size_t i = 0; i < n_dest_; i++) add_out_port();
         gpu::preload_module(device_);
     }
@@ -213,7 +239,7 @@ public:
         hipStream_t s = stream_->get();
         if (in_kind_ == EDGE_HOST_BATCH) {
             if (!in_pool_) in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, device_, sizeof(T), b->capacity, slabs_));
-            if (b->capacity > in_pool_->capacity()) gpu::failwith("KeyBy_EmitterGPU: a batch larger than the first one received");
+            if (b->capacity > in_pool_->capacity()) gpu::failwith("Partition_EmitterGPU: a batch larger than the first one received");
             d = in_pool_->acquire(s);
             *b->header() = b->host_hdr;
             WF_HIP_CHECK(hipMemcpyAsync(d->slab, b->slab, b->bytes_used(), hipMemcpyHostToDevice, s));
@@ -221,7 +247,8 @@ public:
             d->count_on_host = true;
             gpu::release_after(b, s, device_, foreign_);  // the pinned slab may belong to another GPU's context
         } else {
-            if (d->device != device_) gpu::failwith("KeyBy_EmitterGPU: device batch produced on another GPU; place the producer and the keyed operator on the same GPU");
+            if (d->device != device_)
+                gpu::failwith("Partition_EmitterGPU: device batch produced on another GPU; place the producer and the operator behind the partitioning on the same GPU");
             d->ready.edge_wait(s);
         }
         if (n_dest_ == 1) {
@@ -230,7 +257,10 @@ public:
             return;
         }
         std::vector<gpu::Batch*> outs;
-        part_.partition(d, s, outs, kernels_);
+        if constexpr (std::is_void_v<DestFn>)
+            part_.partition(d, s, outs, kernels_);
+        else
+            part_.partition_with(d, s, outs, kernels_, fn_);
         WF_HIP_CHECK(hipGetLastError());
         d->release(s);
         reaper_.tick(s);
@@ -251,10 +281,30 @@ private:
     int device_;
     size_t slabs_;
     gpu::BatchPartitioner<T> part_;
+    fn_t fn_;
     std::unique_ptr<gpu::Stream> stream_;
     gpu::StreamReaper reaper_;
     std::unique_ptr<gpu::BatchPool> in_pool_;
     uint64_t kernels_ = 0;
 };
+template <typename T>
+using KeyBy_EmitterGPU = Partition_EmitterGPU<T, void>;
+
+// Device form of MultiPipe::split (reference: MultiPipe::split, wf/pipegraph.hpp:1893-1958, per-tuple on the CPU): the
+// branch of a tuple is fn(tuple) % cardinality, evaluated on the GPU; every batch becomes one device sub-batch per
+// branch and the branches continue on device-batch edges.  fn: any functor integral(const tuple_t&) callable on the
+// device.  Branches of device batches can be merged again (MultiPipe::merge keeps the batches).
+template <typename F>
+inline MultiPipe& split_gpu(MultiPipe& mp, F fn, size_t cardinality, GPUConfig cfg = GPUConfig()) {
+    using tuple_t = typename meta::split_sig<F>::tuple_t;
+    static_assert(!meta::split_sig<F>::multi, "split_gpu: the splitting function returns one branch index (no multicast on batch edges)");
+    if (cardinality > (size_t)gpu::MAX_PARTITIONS) fatal_error("split_gpu: at most 16 branches");
+    const int device = cfg.device_for(0);
+    const size_t slabs = cfg.pool_slabs;
+    return mp.split_custom(
+        cardinality, typeid(tuple_t), [](edge_kind_t k) { return k == EDGE_HOST_BATCH || k == EDGE_DEVICE_BATCH; },
+        [=](edge_kind_t kind) -> rt::Node* { return new Partition_EmitterGPU<tuple_t, F>(cardinality, kind, device, slabs, fn); }, EDGE_DEVICE_BATCH,
+        batch_adapter_factory<tuple_t>(slabs));
+}
 
 }  // namespace wf

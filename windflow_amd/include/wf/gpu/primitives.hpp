@@ -533,21 +533,5 @@ private:
     DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_, bin_totals_;
 };
 
-// ---------------------------------------------------------------------------
-// one-pass multi-way partition of a tuple batch by destination (K13):
-// dest = routing(hash(key)) in [0, P), P <= 256.  Produces the tuples grouped by
-// destination in stable order plus the P+1 segment offsets - exactly the send
-// buffer / send counts of an all-to-all-v exchange.
-// ---------------------------------------------------------------------------
-template <typename T, typename KeyFn>
-__global__ void __launch_bounds__(BLOCK_THREADS)
-    dest_keys_kernel(const BatchHeader* hdr, const T* data, uint32_t n_dest, uint32_t* dest, uint32_t* idx, KeyFn keyfn, uint32_t hash_shift = 24) {
-    const uint32_t n = hdr->count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        dest[i] = (uint32_t)(((mix64((uint64_t)keyfn(data[i])) >> hash_shift) & 0xffffffull) % n_dest);
-        idx[i] = i;
-    }
-}
-
 }  // namespace gpu
 }  // namespace wf

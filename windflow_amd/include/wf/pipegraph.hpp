@@ -77,6 +77,13 @@ public:
     template <typename F>
     MultiPipe& split(F func, size_t cardinality);
 
+    // Generic form of split (the device split of gpu/split_gpu.hpp builds on it): the edges are first adapted until
+    // `accepts(kind)` holds, then `make(kind)` builds the splitting node fused onto every endpoint - it owns one output
+    // port per branch - and the branches start on edges of kind `branch_kind` with `branch_adapter` as their converter.
+    MultiPipe& split_custom(size_t cardinality, const std::type_info& tuple_type, const std::function<bool(edge_kind_t)>& accepts,
+                            const std::function<rt::Node*(edge_kind_t)>& make, edge_kind_t branch_kind,
+                            std::function<rt::Node*(edge_kind_t)> branch_adapter);
+
     // branch idx of a split MultiPipe
     MultiPipe& select(size_t idx) const {
         if (!is_split_) fatal_error("MultiPipe has not been split, select() cannot be used");
@@ -477,11 +484,16 @@ inline MultiPipe& MultiPipe::merge(MPS&... others) {
         if (mp->is_split_) fatal_error("MultiPipe has been split, merge its branches instead");
         if (mp->out_type_ == nullptr || *mp->out_type_ != *out_type_) fatal_error("MultiPipes to be merged must have the same output type");
     }
-    // batches are converted back to tuples before a merge
-    for (MultiPipe* mp : ops) mp->adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
+    // operands that carry batches keep them: every operand is brought down to the lowest kind among them (device
+    // batches -> host batches -> tuples), so a merge of device-batch branches stays on the device
+    edge_kind_t common = tail_kind_;
+    for (MultiPipe* mp : ops) common = std::min(common, mp->tail_kind_);
+    for (MultiPipe* mp : ops) mp->adapt_tails([common](edge_kind_t k) { return k <= common; });
     MultiPipe* merged = graph_->new_mp();
     merged->has_source_ = true;
     merged->out_type_ = out_type_;
+    merged->tail_kind_ = common;
+    merged->tail_adapter_ = tail_adapter_;
     merged->force_shuffle_ = true;  // reference: MultiPipe ctor II, pipegraph.hpp:298-329
     for (MultiPipe* mp : ops) {
         merged->tails_.insert(merged->tails_.end(), mp->tails_.begin(), mp->tails_.end());
@@ -495,16 +507,24 @@ inline MultiPipe& MultiPipe::merge(MPS&... others) {
 
 template <typename F>
 inline MultiPipe& MultiPipe::split(F func, size_t cardinality) {
+    using tuple_t = typename meta::split_sig<F>::tuple_t;
+    return split_custom(
+        cardinality, typeid(tuple_t), [](edge_kind_t k) { return k == EDGE_TUPLE; },
+        [func, cardinality](edge_kind_t) -> rt::Node* { return new Splitting_Emitter<tuple_t, F>(func, cardinality); }, EDGE_TUPLE, nullptr);
+}
+
+inline MultiPipe& MultiPipe::split_custom(size_t cardinality, const std::type_info& tuple_type, const std::function<bool(edge_kind_t)>& accepts,
+                                          const std::function<rt::Node*(edge_kind_t)>& make, edge_kind_t branch_kind,
+                                          std::function<rt::Node*(edge_kind_t)> branch_adapter) {
     check_editable("it cannot be split");
     if (tails_.empty() || fresh_from_split_) fatal_error("MultiPipe is empty, it cannot be split");
     if (cardinality < 2) fatal_error("split() needs at least two branches");
-    using tuple_t = typename meta::split_sig<F>::tuple_t;
-    if (*out_type_ != typeid(tuple_t)) fatal_error("input type of the splitting function does not match the output type of the MultiPipe");
-    adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
+    if (*out_type_ != tuple_type) fatal_error("input type of the splitting function does not match the output type of the MultiPipe");
+    adapt_tails(accepts);
     rt::Graph& g = graph_->graph_;
     std::vector<rt::Node*> splitters;
     for (Endpoint& e : tails_) {
-        auto* s = g.adopt(new Splitting_Emitter<tuple_t, F>(func, cardinality));
+        rt::Node* s = g.adopt(make(tail_kind_));
         g.connect_fused(e.node, e.port, s);
         splitters.push_back(s);
     }
@@ -514,6 +534,8 @@ inline MultiPipe& MultiPipe::split(F func, size_t cardinality) {
         c->has_source_ = true;
         c->out_type_ = out_type_;
         c->fresh_from_split_ = true;
+        c->tail_kind_ = branch_kind;
+        c->tail_adapter_ = branch_adapter;
         c->dot_tail_ = dot_tail_;
         c->split_label_ = "branch " + std::to_string(b);
         for (rt::Node* s : splitters) c->tails_.push_back({s, b});
