@@ -75,6 +75,9 @@ def parse_args():
                    help="keyby: tuples are re-partitioned by key across the GPUs with Exchange_GPU (RCCL all-to-all over xGMI) - what "
                         "a keyed operator needs when the sources cannot pre-partition; dp: keys are partitioned at ingestion, every GPU "
                         "aggregates its own sources and no byte crosses xGMI; auto: keyby when N > 1 (win_agg, ysb), dp on one GPU")
+    p.add_argument("--transport", default=os.environ.get("WF_BENCH_TRANSPORT", "rccl"), choices=["rccl", "ipc"],
+                   help="keyby data plane: rccl = grouped ncclSend/ncclRecv (RCCL over xGMI); ipc = peers pull each other's device buffers "
+                        "through hipIpc memory handles (no collective library; also works for ranks that share a GPU)")
     p.add_argument("--dp-probe-steps", type=int, default=int(os.environ.get("WF_BENCH_DP_PROBE", "3")),
                    help="N>1, keyby mode: after the timed run, also time this many steps of the dp pipeline (no exchange) in child "
                         "processes and report them as an extra field (0 disables)")
@@ -265,7 +268,7 @@ def main():
         if args.parallelism == "keyby":
             from windflow_amd import parallel as wfpar
 
-            transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
+            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
         # n_keys: per source when the sources own disjoint key sets, the whole key space (of this GPU) when they share it
         pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source * args.sources if args.shared_keys else keys_per_source,
                                   win, slide, not args.count_based, 0, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
@@ -284,7 +287,7 @@ def main():
         if args.parallelism == "keyby":
             from windflow_amd import parallel as wfpar
 
-            transport = wfpar.rccl_transport(wfpar.DistEnv(), local_rank)
+            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
         pipe = ext.YsbPipeline(local_rank, args.sources, args.batch, args.ysb_period_us, args.ysb_delay_us, args.inflight,
                                args.agg_replicas or 1, transport)
     else:
@@ -340,6 +343,7 @@ def main():
                 "global_batch": tuples_per_step_gpu * world,
                 "seq_len": args.batch,
                 "parallelism": "%s%d" % (args.parallelism, world),
+                **({"transport": args.transport} if args.parallelism == "keyby" else {}),
                 "sources_per_gpu": args.sources,
                 "keys_per_gpu": args.keys if args.pipeline == "win_seq" else keys_per_source * args.sources,
                 "key_distribution": args.key_dist + (" alpha=%g" % args.zipf_alpha if args.key_dist == "zipf" else ""),

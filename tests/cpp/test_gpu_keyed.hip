@@ -293,10 +293,52 @@ int main(int argc, char** argv) {
              << 2 * per_replica << ")" << (ok ? "  OK" : "  FAILED") << endl;
         failures += !ok;
     }
-    // ---- E (only with 2+ GPUs): scenario B with the replicas of the two keyed operators placed on different GPUs; the
-    //      sub-batches of the device KeyBy cross GPUs with peer copies ----
-    // opt-in (WF_TEST_MULTI_GPU=1): this path has not run on real multi-GPU hardware yet
-    if (gpu::device_count() >= 2 && std::getenv("WF_TEST_MULTI_GPU") != nullptr) {
+    // ---- G: split and merge WITHOUT leaving the device: split_gpu partitions every batch by a device functor, the branches
+    //      run their own GPU operators on device batches and are merged again in front of a GPU filter ----
+    for (size_t run = 0; run < runs; run++) {
+        struct BySign {
+            __host__ __device__ size_t operator()(const tuple_t& t) const { return t.value < 0 ? 0 : 1; }
+        };
+        const size_t p0 = (size_t)dp(rng), p1 = (size_t)dp(rng), p2 = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        PipeGraph g("keyed_g", Mode::DEFAULT);
+        auto src = BatchSource_Builder(Gen(n, keys)).withName("src").withParallelism(2).withBatch(batch).build_unique();
+        MultiPipe& mp = g.add_source(*src);
+        split_gpu(mp, BySign(), 2);
+        auto neg = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = -3 * t.value; }).withName("neg").withParallelism(p0).build_unique();
+        auto pos = MapGPU_Builder([] __host__ __device__(tuple_t & t) { t.value = t.value + 7; }).withName("pos").withParallelism(p1).build_unique();
+        MultiPipe& b0 = mp.select(0);
+        b0.add(*neg);
+        MultiPipe& b1 = mp.select(1);
+        b1.add(*pos);
+        MultiPipe& m = b0.merge(b1);
+        auto fil = FilterGPU_Builder([] __host__ __device__(const tuple_t& t) { return t.value % 2 == 0; }).withName("even").withParallelism(p2).build_unique();
+        m.add(*fil);
+        std::atomic<long> sum{0}, cnt{0};
+        Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                        if (o) {
+                            sum += o->value;
+                            cnt++;
+                        }
+                    }).withParallelism(1).build();
+        m.add_sink(sink);
+        g.run();
+        long e_sum = 0, e_cnt = 0;
+        for (auto& t : stream) {
+            const int64_t v = t.value < 0 ? -3 * t.value : t.value + 7;
+            if (v % 2 == 0) {
+                e_sum += 2 * v;  // two source replicas emit the stream
+                e_cnt += 2;
+            }
+        }
+        const bool ok = sum == e_sum && cnt == e_cnt;
+        cout << "G device split/merge par=" << p0 << "," << p1 << "," << p2 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << e_sum
+             << " " << e_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
+        failures += !ok;
+    }
+    // ---- E (whenever 2+ GPUs are visible; WF_SKIP_MULTI_GPU=1 opts out): scenario B with the replicas of the two keyed
+    //      operators placed on different GPUs; the sub-batches of the device KeyBy cross GPUs with peer copies ----
+    if (gpu::device_count() >= 2 && std::getenv("WF_SKIP_MULTI_GPU") == nullptr) {
         const size_t batch = 1024;
         PipeGraph g("keyed_e", Mode::DEFAULT);
         auto src = BatchSource_Builder(Gen(n, keys)).withParallelism(1).withBatch(batch).build_unique();

@@ -1,5 +1,9 @@
 """Distributed layer on one GPU: in-process multi-rank exchange (LocalTransport), RCCL with world size 1."""
+import json
 import math
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -144,3 +148,53 @@ def test_ysb_over_exchange(ext, world, sources, lanes, split_merge):
     if world > 1:
         assert all(s["sink_tuples"] > 0 for s in stats), "some rank owns no campaign"
         assert all(s["exchange_tuples_sent"] > 0 for s in stats)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch_ranks(world, kind, pipeline, lanes, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), kind, pipeline, str(lanes)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=110, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("world,lanes", [(2, 1), (3, 2)])
+def test_win_agg_across_processes_ipc(world, lanes):
+    """one PROCESS per rank (torch.distributed.run), control board in POSIX shared memory, data pulled through hipIpc
+    handles; the ranks share the GPU of the box when it has fewer GPUs than ranks"""
+    out = _launch_ranks(world, "ipc", "win_agg", lanes, 29611 + world)
+    assert out["transport"] == "ipc" and out["world"] == world
+    stats = out["ranks"]
+    total, windows = _expected_single_source(2 * 40_000, 50, 8, 2)
+    assert sum(s["sink_tuples"] for s in stats) == world * 2 * windows
+    assert sum(s["sink_value_sum"] for s in stats) == pytest.approx(world * 2 * total, rel=1e-12)
+    assert all(s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
+    assert all(s["exchange_tuples_sent"] > 0 and s["sink_tuples"] > 0 for s in stats)
+
+
+def test_ysb_across_processes_ipc():
+    out = _launch_ranks(2, "ipc", "ysb", 2, 29621)
+    stats = out["ranks"]
+    views, results = _ysb_expected(2 * 600_000, 2 * 2, 10)
+    assert sum(s["counted_views"] for s in stats) == views
+    assert sum(s["sink_tuples"] for s in stats) == results
+    assert all(s["dropped"] == 0 and s["overflow"] == 0 for s in stats)
+
+
+def test_win_agg_across_gpus_rccl():
+    """RCCL between distinct devices (grouped ncclSend / ncclRecv over xGMI): runs whenever the box has 2+ GPUs"""
+    n_gpus = torch.cuda.device_count()
+    if n_gpus < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    world = min(n_gpus, 4)
+    out = _launch_ranks(world, "rccl", "win_agg", 2, 29631)
+    assert out["transport"] == "rccl"
+    stats = out["ranks"]
+    total, windows = _expected_single_source(2 * 40_000, 50, 8, 2)
+    assert sum(s["sink_tuples"] for s in stats) == world * 2 * windows
+    assert sum(s["sink_value_sum"] for s in stats) == pytest.approx(world * 2 * total, rel=1e-12)
+    assert all(s["overflow"] == 0 and s["table_full"] == 0 for s in stats)

@@ -975,6 +975,10 @@ PYBIND11_MODULE(_C, m) {
     py::class_<dist::LocalFabric, std::shared_ptr<dist::LocalFabric>>(m, "LocalFabric").def(py::init<int>(), py::arg("world"));
     m.def("rccl_create_id", &rccl_create_id);
     m.def("rccl_transport", &make_rccl_transport, py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("device"));
+    m.def("ipc_transport", [](int rank, int world, const std::string& token, int device) -> std::shared_ptr<dist::Transport> {
+        py::gil_scoped_release rel;
+        return std::make_shared<dist::IpcTransport>(rank, world, token, device);
+    }, py::arg("rank"), py::arg("world"), py::arg("token"), py::arg("device"));
     m.def("local_transport", [](std::shared_ptr<dist::LocalFabric> f, int rank) -> std::shared_ptr<dist::Transport> {
         return std::make_shared<dist::LocalTransport>(std::move(f), rank);
     }, py::arg("fabric"), py::arg("rank"));

@@ -323,7 +323,7 @@ private:
         }
         st.row.step = local_step_done_;
         st.row.capacity = my_cap_;
-        st.row.send_base = (uint64_t)(uintptr_t)st.buf->template data<tuple_t>();
+        tr_->describe_send(st.buf->slab, st.buf->template data<tuple_t>(), st.row);
         xstats_->bundles += take.size();
         return true;
     }

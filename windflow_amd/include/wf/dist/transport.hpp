@@ -35,6 +35,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -67,15 +68,19 @@ struct ControlRow {
     uint64_t watermark;   // greatest timestamp of the rank's batch of this round
     uint64_t created_ns;  // when the rank's batch of this round was opened (latency accounting)
     uint64_t capacity;    // largest batch capacity the rank has seen (sizes the receive slabs)
-    uint64_t send_base;   // LocalTransport: address of the rank's send buffer for this round
-    uint64_t aux[2];
+    uint64_t send_base;   // pull transports: address of the rank's send buffer for this round (in the sender's address space)
+    uint64_t ipc_offset;  // IpcTransport: offset of send_base inside the allocation named by ipc_handle
+    uint64_t aux;
+    unsigned char ipc_handle[64];  // IpcTransport: hipIpcMemHandle_t of the allocation that holds the send buffer
 };
+static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ControlRow::ipc_handle too small");
 
 // Rounds are numbered 0, 1, 2...; the board keeps DEPTH of them.  A rank may publish round r once every rank has
 // collected round r - DEPTH (its slot is then free); tags make rows visible with release / acquire ordering.
 class ControlBoard {
 public:
     static constexpr uint64_t DEPTH = 8;
+    static constexpr size_t GATHER_WORDS = 64;
     struct Slot {
         std::atomic<uint64_t> tag;  // round + 1 when the row is valid
         ControlRow row;
@@ -85,6 +90,7 @@ public:
         std::atomic<uint64_t> collected[MAX_WORLD];      // rounds the rank has collected (next round to collect)
         std::atomic<uint64_t> acked[DEPTH][MAX_WORLD];   // data plane: peers that are done with rank's send buffer of the round
         std::atomic<uint64_t> barrier_count, barrier_gen;
+        uint64_t gather[MAX_WORLD][GATHER_WORDS];        // scratch of the blocking helpers (between two barriers)
         Slot slots[DEPTH][MAX_WORLD];
     };
     static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control board needs lock-free 64-bit atomics");
@@ -132,12 +138,58 @@ public:
             while (sh_->barrier_gen.load(std::memory_order_acquire) == gen) std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
     }
+    // every rank contributes `words` (<= GATHER_WORDS) 64-bit words; blocking
+    void all_gather(const uint64_t* mine, uint64_t* out, size_t words) {
+        std::memcpy(sh_->gather[rank_], mine, words * sizeof(uint64_t));
+        barrier();
+        for (int r = 0; r < world_; r++) std::memcpy(out + (size_t)r * words, sh_->gather[r], words * sizeof(uint64_t));
+        barrier();
+    }
     int rank() const { return rank_; }
     int world() const { return world_; }
 
 private:
     Shared* sh_;
     int rank_, world_;
+};
+
+// The control board of a multi-process job: POSIX shared memory named after a token every rank of the job knows (a fresh
+// segment is zero-filled, which is the board's initial state).  The constructor returns once every rank has mapped it.
+class ShmBoard {
+public:
+    ShmBoard(const std::string& token, int rank, int world) {
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char c : token) h = (h ^ c) * 1099511628211ull;
+        const std::string name = "/wf_board_" + std::to_string(h);
+        const int fd = shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) gpu::failwith("ShmBoard: shm_open failed for the control board");
+        if (ftruncate(fd, (off_t)sizeof(ControlBoard::Shared)) != 0) gpu::failwith("ShmBoard: ftruncate failed for the control board");
+        void* p = mmap(nullptr, sizeof(ControlBoard::Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) gpu::failwith("ShmBoard: mmap failed for the control board");
+        shared_ = static_cast<ControlBoard::Shared*>(p);
+        board_.reset(new ControlBoard(shared_, rank, world));
+        // nobody uses the board before everybody has mapped it; then the name can go (the mapping stays)
+        shared_->attached.fetch_add(1, std::memory_order_acq_rel);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        while (shared_->attached.load(std::memory_order_acquire) < (uint64_t)world) {
+            if (std::chrono::steady_clock::now() > deadline) gpu::failwith("ShmBoard: timed out waiting for the other ranks to map the control board");
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        board_->barrier();
+        if (rank == 0) shm_unlink(name.c_str());
+    }
+    ~ShmBoard() {
+        board_.reset();
+        if (shared_) munmap(shared_, sizeof(ControlBoard::Shared));
+    }
+    ShmBoard(const ShmBoard&) = delete;
+    ShmBoard& operator=(const ShmBoard&) = delete;
+    std::unique_ptr<ControlBoard> take_board() { return std::move(board_); }
+
+private:
+    ControlBoard::Shared* shared_ = nullptr;
+    std::unique_ptr<ControlBoard> board_;
 };
 
 // per-peer slices of one all-to-all-v (device pointers, byte counts)
@@ -159,6 +211,12 @@ public:
     ControlBoard& board() { return *board_; }
     // all-to-all-v of round `round`, enqueued on `s` (returns without waiting).  `rows` are the collected rows of the round.
     virtual void exchange(uint64_t round, const PeerSlices& p, const ControlRow* rows, hipStream_t s) = 0;
+    // called while a round's row is filled: `buf_base` is the start of the device allocation that holds the send buffer,
+    // `send` the first byte the peers will read
+    virtual void describe_send(const void* buf_base, const void* send, ControlRow& row) {
+        (void)buf_base;
+        row.send_base = (uint64_t)(uintptr_t)send;
+    }
     // true: peers read this rank's send buffer on their own streams, from the moment the round's row is on the board -
     // a row must not be published before the buffer is complete
     virtual bool pulls() const { return false; }
@@ -199,33 +257,13 @@ public:
         WF_RCCL_CHECK(ncclCommInitRank(&comm_, world, id, rank));
         stage_dev_.resize(STAGE_WORDS * (size_t)(world + 1));
         stage_host_.resize(STAGE_WORDS * (size_t)(world + 1));
-        // the control board lives in POSIX shared memory named after the unique id (every rank of the job derives the
-        // same name; a fresh segment is zero-filled, which is the board's initial state)
-        uint64_t h = 1469598103934665603ull;
-        for (unsigned char c : id_bytes) h = (h ^ c) * 1099511628211ull;
-        shm_name_ = "/wf_board_" + std::to_string(h);
-        const int fd = shm_open(shm_name_.c_str(), O_CREAT | O_RDWR, 0600);
-        if (fd < 0) gpu::failwith("RcclTransport: shm_open failed for the control board");
-        if (ftruncate(fd, (off_t)sizeof(ControlBoard::Shared)) != 0) gpu::failwith("RcclTransport: ftruncate failed for the control board");
-        void* p = mmap(nullptr, sizeof(ControlBoard::Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (p == MAP_FAILED) gpu::failwith("RcclTransport: mmap failed for the control board");
-        shared_ = static_cast<ControlBoard::Shared*>(p);
-        board_.reset(new ControlBoard(shared_, rank, world));
-        // nobody uses the board before everybody has mapped it; then the name can go (the mapping stays)
-        shared_->attached.fetch_add(1, std::memory_order_acq_rel);
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
-        while (shared_->attached.load(std::memory_order_acquire) < (uint64_t)world) {
-            if (std::chrono::steady_clock::now() > deadline) gpu::failwith("RcclTransport: timed out waiting for the other ranks to map the control board");
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
-        }
-        board_->barrier();
-        if (rank == 0) shm_unlink(shm_name_.c_str());
+        // the control board lives in POSIX shared memory named after the unique id (every rank of the job has it)
+        shm_.reset(new ShmBoard(id_bytes, rank, world));
+        board_ = shm_->take_board();
         for (auto& e : round_events_) e.reset(new gpu::Event());
     }
     ~RcclTransport() override {
         if (comm_) (void)ncclCommDestroy(comm_);
-        if (shared_) munmap(shared_, sizeof(ControlBoard::Shared));
     }
     const char* name() const override { return "rccl"; }
 
@@ -272,8 +310,7 @@ private:
     std::mutex m_;  // one collective at a time per communicator
     gpu::DeviceBuffer<uint64_t> stage_dev_;
     gpu::PinnedBuffer<uint64_t> stage_host_;
-    std::string shm_name_;
-    ControlBoard::Shared* shared_ = nullptr;
+    std::unique_ptr<ShmBoard> shm_;
     std::unique_ptr<gpu::Event> round_events_[ControlBoard::DEPTH];
 };
 
@@ -409,6 +446,125 @@ private:
         }
     }
     std::shared_ptr<LocalFabric> fabric_;
+    std::deque<std::pair<uint64_t, std::unique_ptr<gpu::Event>>> pending_;
+};
+
+// One PROCESS per rank, no collective library in the data path: a rank publishes the IPC handle of the device allocation
+// that holds its send buffer, the peers map it once (hipIpcOpenMemHandle; the mapping is cached per allocation) and PULL
+// their slices with device copies on their own streams - over xGMI when the ranks sit on different GPUs, inside the card
+// when they share one (which RCCL refuses: "duplicate GPU").  The direct load/store path SURVEY.md par. 5.8 asks for, and the
+// multi-process test vehicle of the control plane on a one-GPU box.
+class IpcTransport : public Transport {
+public:
+    // `token`: any string all ranks of the job share and no other job on the host uses (names the control board)
+    IpcTransport(int rank, int world, const std::string& token, int device) : device_(device) {
+        if (world < 1 || world > MAX_WORLD) gpu::failwith("IpcTransport: world size out of range");
+        rank_ = rank;
+        world_ = world;
+        WF_HIP_CHECK(hipSetDevice(device_));
+        shm_.reset(new ShmBoard("ipc:" + token, rank, world));
+        board_ = shm_->take_board();
+    }
+    ~IpcTransport() override {
+        for (auto& m : mapped_) (void)hipIpcCloseMemHandle(m.ptr);
+    }
+    const char* name() const override { return "ipc"; }
+    bool pulls() const override { return true; }
+
+    void describe_send(const void* buf_base, const void* send, ControlRow& row) override {
+        row.send_base = (uint64_t)(uintptr_t)send;
+        row.ipc_offset = (uint64_t)((const char*)send - (const char*)buf_base);
+        auto it = exported_.find(buf_base);
+        if (it == exported_.end()) {
+            hipIpcMemHandle_t h;
+            WF_HIP_CHECK(hipIpcGetMemHandle(&h, const_cast<void*>(buf_base)));
+            it = exported_.emplace(buf_base, h).first;
+        }
+        std::memset(row.ipc_handle, 0, sizeof(row.ipc_handle));
+        std::memcpy(row.ipc_handle, &it->second, sizeof(hipIpcMemHandle_t));
+    }
+
+    void exchange(uint64_t round, const PeerSlices& p, const ControlRow* rows, hipStream_t s) override {
+        bool copied = false;
+        for (int peer = 0; peer < world_; peer++) {
+            if (p.recv_bytes[peer] == 0) continue;
+            const char* base = (peer == rank_) ? reinterpret_cast<const char*>((uintptr_t)rows[peer].send_base)
+                                               : static_cast<const char*>(map_peer(peer, rows[peer].ipc_handle)) + rows[peer].ipc_offset;
+            WF_HIP_CHECK(hipMemcpyAsync(p.recv[peer], base + p.pull_offset[peer], p.recv_bytes[peer], hipMemcpyDeviceToDevice, s));
+            copied = true;
+        }
+        if (!copied) {
+            for (int peer = 0; peer < world_; peer++) board_->ack(round, peer);
+            return;
+        }
+        std::unique_ptr<gpu::Event> e(new gpu::Event());
+        e->record(s);
+        pending_.push_back({round, std::move(e)});
+        poll_acks();
+    }
+    bool sends_done(uint64_t round) override {
+        poll_acks();
+        return board_->acks(round) >= (uint64_t)world_;
+    }
+    void quiesce(hipStream_t s) override {
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+        poll_acks();
+    }
+    void all_gather_host(const uint64_t* mine, uint64_t* out, size_t words, hipStream_t) override {
+        if (words > ControlBoard::GATHER_WORDS) gpu::failwith("IpcTransport::all_gather_host: too many words");
+        board_->all_gather(mine, out, words);
+    }
+    // setup-time helper (a few words at a time through the control board)
+    void all_reduce_sum(double* dev, size_t n, hipStream_t s) override {
+        std::vector<double> host(n);
+        WF_HIP_CHECK(hipMemcpyAsync(host.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<uint64_t> all(ControlBoard::GATHER_WORDS * (size_t)world_);
+        for (size_t i = 0; i < n; i += ControlBoard::GATHER_WORDS) {
+            const size_t w = std::min(ControlBoard::GATHER_WORDS, n - i);
+            board_->all_gather(reinterpret_cast<const uint64_t*>(host.data() + i), all.data(), w);
+            for (size_t j = 0; j < w; j++) {
+                double acc = 0.0;
+                for (int r = 0; r < world_; r++) {
+                    double v;
+                    std::memcpy(&v, &all[(size_t)r * w + j], sizeof(v));
+                    acc += v;
+                }
+                host[i + j] = acc;
+            }
+        }
+        WF_HIP_CHECK(hipMemcpyAsync(dev, host.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+        WF_HIP_CHECK(hipStreamSynchronize(s));
+    }
+
+private:
+    struct Mapped {
+        int peer;
+        unsigned char handle[64];
+        void* ptr;
+    };
+    void* map_peer(int peer, const unsigned char* handle) {
+        for (const Mapped& m : mapped_)
+            if (m.peer == peer && std::memcmp(m.handle, handle, 64) == 0) return m.ptr;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handle, sizeof(h));
+        Mapped m;
+        m.peer = peer;
+        std::memcpy(m.handle, handle, 64);
+        WF_HIP_CHECK(hipIpcOpenMemHandle(&m.ptr, h, hipIpcMemLazyEnablePeerAccess));
+        mapped_.push_back(m);
+        return m.ptr;
+    }
+    void poll_acks() {
+        while (!pending_.empty() && pending_.front().second->done()) {
+            for (int peer = 0; peer < world_; peer++) board_->ack(pending_.front().first, peer);
+            pending_.pop_front();
+        }
+    }
+    int device_;
+    std::unique_ptr<ShmBoard> shm_;
+    std::map<const void*, hipIpcMemHandle_t> exported_;
+    std::vector<Mapped> mapped_;
     std::deque<std::pair<uint64_t, std::unique_ptr<gpu::Event>>> pending_;
 };
 

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 from .. import load_ext
 
-__all__ = ["DistEnv", "init_distributed", "rccl_transport", "local_fabric", "local_transport", "shutdown"]
+__all__ = ["DistEnv", "init_distributed", "rccl_transport", "ipc_transport", "local_fabric", "local_transport", "shutdown"]
 
 
 class DistEnv:
@@ -57,6 +57,18 @@ def rccl_transport(env=None, device=None):
         sys.stdout.flush()
         os.dup2(saved, 1)
         os.close(saved)
+
+
+def ipc_transport(env=None, device=None):
+    """Create this rank's IPC transport (one process per rank, peers pull from each other's device buffers through
+    hipIpc memory handles: works across GPUs over xGMI and between ranks that share a GPU); rank 0 mints the job token."""
+    ext = load_ext()
+    env = env or DistEnv()
+    device = env.local_rank if device is None else device
+    box = ["%d-%s" % (os.getpid(), os.urandom(8).hex()) if env.rank == 0 else None]
+    if env.world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return ext.ipc_transport(env.rank, env.world, box[0], device)
 
 
 def local_fabric(world):
