@@ -75,9 +75,11 @@ def parse_args():
                    help="keyby: tuples are re-partitioned by key across the GPUs with Exchange_GPU (RCCL all-to-all over xGMI) - what "
                         "a keyed operator needs when the sources cannot pre-partition; dp: keys are partitioned at ingestion, every GPU "
                         "aggregates its own sources and no byte crosses xGMI; auto: keyby when N > 1 (win_agg, ysb), dp on one GPU")
-    p.add_argument("--transport", default=os.environ.get("WF_BENCH_TRANSPORT", "rccl"), choices=["rccl", "ipc"],
+    p.add_argument("--transport", default=os.environ.get("WF_BENCH_TRANSPORT", "auto"), choices=["auto", "rccl", "ipc"],
                    help="keyby data plane: rccl = grouped ncclSend/ncclRecv (RCCL over xGMI); ipc = peers pull each other's device buffers "
-                        "through hipIpc memory handles (no collective library; also works for ranks that share a GPU)")
+                        "through hipIpc memory handles (no collective library; also works for ranks that share a GPU); auto (N > 1) = rccl "
+                        "if a short self-test of it in child processes passes on every rank, else ipc, else the run falls back to dp and says so")
+    p.add_argument("--preflight", default="", help=argparse.SUPPRESS)  # internal: run the transport self-test and exit
     p.add_argument("--dp-probe-steps", type=int, default=int(os.environ.get("WF_BENCH_DP_PROBE", "3")),
                    help="N>1, keyby mode: after the timed run, also time this many steps of the dp pipeline (no exchange) in child "
                         "processes and report them as an extra field (0 disables)")
@@ -204,6 +206,45 @@ def run_dp_probe(args, world, limit_s=90):
     return {"status": "ok (this rank printed no result)"}
 
 
+def run_preflight(kind, world, local_rank):
+    """Child-process body of the transport self-test: a tiny keyby pipeline over `kind`; exit status 0 = it moved tuples
+    between the ranks and lost none."""
+    from windflow_amd import load_ext, parallel as wfpar
+
+    env = wfpar.init_distributed()
+    transport = (wfpar.ipc_transport if kind == "ipc" else wfpar.rccl_transport)(env, local_rank)
+    pipe = load_ext().WinAggPipeline(local_rank, 2, 4096, 64, 8, 2, False, 0, 4, transport, 2)
+    pipe.step(40_000)
+    pipe.step(40_000)
+    pipe.close()
+    st = pipe.stats()
+    ok = st["overflow"] == 0 and st["table_full"] == 0 and st["exchange_tuples_sent"] == 160_000 and st["sink_tuples"] > 0
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    wfpar.shutdown()
+    return 0 if int(t.item()) == 1 else 1
+
+
+def preflight_ok(kind, world, port_offset, limit_s=150):
+    """Run the self-test of transport `kind` in a child of every rank; True only if every rank's child succeeded."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--preflight", kind, "--gpus", str(world)]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
+        ok, why = r.returncode == 0, (r.stderr or "")[-200:]
+    except subprocess.TimeoutExpired:
+        ok, why = False, "timeout"
+    if not ok:
+        print("[bench] %s self-test failed on rank %s: %s" % (kind, os.environ.get("RANK", "0"), why), file=sys.stderr, flush=True)
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def main():
     args = parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,6 +282,25 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
+    if args.preflight:
+        raise SystemExit(run_preflight(args.preflight, world, local_rank))
+    fallback_note = None
+    if args.parallelism == "keyby" and args.transport == "auto":
+        if world == 1:
+            args.transport = "rccl"
+        else:
+            # the data plane between distinct GPUs cannot be rehearsed on a one-GPU development box: try it in child processes
+            # first, so that a fabric problem (an RCCL abort, a hang inside a collective) costs a fallback, not the run
+            chosen = None
+            for i, kind in enumerate(("rccl", "ipc")):
+                if preflight_ok(kind, world, 23 + 7 * i):
+                    chosen = kind
+                    break
+            if chosen is None:
+                fallback_note = "keyby self-tests failed for rccl and ipc: ran dp (no exchange)"
+                args.parallelism = "dp"
+            else:
+                args.transport = chosen
     if world > 1 and not args.no_cpu_partition:
         # Give every rank its own contiguous slice of the CPUs this job may use (the runtime's source, operator
         # and sink threads inherit it): on a two-socket node that keeps the pinned slabs and the threads that
@@ -344,6 +404,7 @@ def main():
                 "seq_len": args.batch,
                 "parallelism": "%s%d" % (args.parallelism, world),
                 **({"transport": args.transport} if args.parallelism == "keyby" else {}),
+                **({"fallback": fallback_note} if fallback_note else {}),
                 "sources_per_gpu": args.sources,
                 "keys_per_gpu": args.keys if args.pipeline == "win_seq" else keys_per_source * args.sources,
                 "key_distribution": args.key_dist + (" alpha=%g" % args.zipf_alpha if args.key_dist == "zipf" else ""),
