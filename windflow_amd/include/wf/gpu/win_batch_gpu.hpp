@@ -584,14 +584,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 
 // ---- 8. carry + state --------------------------------------------------------------------------------
+// A run's carry (the tail of its segment that open windows still need) is copied by `chunks` waves, WB_COMMIT_CHUNK words
+// each, so that a few long carries (few keys, long windows) spread over the whole chip; wave 0 of a run writes its state.
+constexpr uint32_t WB_COMMIT_CHUNK = 512;  // 8-byte words per wave
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     wb_commit_kernel(const unsigned long long* table, WinKeyState* states, const WinRun* runs, const uint32_t* n_fire, const uint32_t* win_off,
-                     const T* work, T* carry, const WinCtl* ctl, WinCounters* ctr, WinGeometry g) {
+                     const T* work, T* carry, const WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t chunks) {
+    using W = std::conditional_t<sizeof(T) % 8 == 0 && alignof(T) % 8 == 0, uint64_t,
+                                 std::conditional_t<sizeof(T) % 4 == 0 && alignof(T) % 4 == 0, uint32_t, unsigned char>>;
+    constexpr uint32_t WPT = sizeof(T) / sizeof(W);
     const uint32_t n_runs = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const uint32_t lane = (uint32_t)lane_id();
-    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < n_runs; r += waves_total) {
+    const uint64_t units = (uint64_t)n_runs * chunks;
+    for (uint64_t u = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); u < units; u += waves_total) {
+        const uint32_t r = (uint32_t)(u / chunks), c = (uint32_t)(u % chunks);
         const WinRun run = runs[r];
         const WinAssignD wa = win_assign(g, (uint64_t)table[run.slot]);
         // windows that did not fit the output batch are not fired now: they stay open (their tuples are carried) and fire
@@ -605,24 +614,37 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t p0 = win_lower_bound(seg, sl, keep_from, g.is_tb);
         T* dst = carry + (size_t)run.dense * g.carry_cap;
         uint32_t kept = 0;
-        for (uint32_t c0 = p0; c0 < sl; c0 += WAVE) {
-            const uint32_t p = c0 + lane;
-            bool keep = p < sl;
-            if (keep && g.win < g.slide) {  // hopping windows: tuples in the gaps belong to no window
-                const uint64_t o = win_ord(seg[p], g.is_tb);
-                keep = o >= wa.initial_id && (o - wa.initial_id) % g.slide < g.win;
+        if (g.win < g.slide) {
+            // hopping windows: tuples in the gaps belong to no window; compacted by one wave
+            if (c != 0) continue;
+            for (uint32_t c0 = p0; c0 < sl; c0 += WAVE) {
+                const uint32_t p = c0 + lane;
+                bool keep = p < sl;
+                if (keep) {
+                    const uint64_t o = win_ord(seg[p], g.is_tb);
+                    keep = o >= wa.initial_id && (o - wa.initial_id) % g.slide < g.win;
+                }
+                const unsigned long long m = __ballot(keep);
+                const uint32_t pos = kept + (uint32_t)__popcll(m & lanemask_lt());
+                if (keep) {
+                    if (pos < g.carry_cap)
+                        dst[pos] = seg[p];
+                    else
+                        atomicAdd(&ctr->carry_overflow, 1u);
+                }
+                kept += (uint32_t)__popcll(m);
             }
-            const unsigned long long m = __ballot(keep);
-            const uint32_t pos = kept + (uint32_t)__popcll(m & lanemask_lt());
-            if (keep) {
-                if (pos < g.carry_cap)
-                    dst[pos] = seg[p];
-                else
-                    atomicAdd(&ctr->carry_overflow, 1u);
-            }
-            kept += (uint32_t)__popcll(m);
+        } else {
+            kept = sl - p0;
+            const uint32_t fit = kept < g.carry_cap ? kept : g.carry_cap;
+            const uint32_t words = fit * WPT;
+            const uint32_t lo = c * WB_COMMIT_CHUNK, hi = lo + WB_COMMIT_CHUNK < words ? lo + WB_COMMIT_CHUNK : words;
+            const W* __restrict__ src_w = reinterpret_cast<const W*>(seg + p0);
+            W* __restrict__ dst_w = reinterpret_cast<W*>(dst);
+            for (uint32_t w = lo + lane; w < hi; w += WAVE) dst_w[w] = src_w[w];
+            if (c == 0 && lane == 0 && kept > g.carry_cap) atomicAdd(&ctr->carry_overflow, kept - g.carry_cap);
         }
-        if (lane == 0) {
+        if (c == 0 && lane == 0) {
             WinKeyState* st = &states[run.slot];
             st->next_lwid = next_lwid;
             st->max_ord = run.max_ord;
@@ -803,8 +825,13 @@ public:
         hipLaunchKernelGGL(wb_plan_kernel, dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), runs_.data(), n_fire_.data(), ctl_.data(), g_);
         exclusive_scan_u32(n_fire_.data(), win_off_.data(), runs_upper, &ctl_.data()->win_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
         evaluate(work_.data(), out, s, 0);
-        hipLaunchKernelGGL((wb_commit_kernel<T>), dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), states_.data(), runs_.data(), n_fire_.data(),
-                           win_off_.data(), work_.data(), carry_.data(), ctl_.data(), counters_.data(), g_);
+        {
+            const size_t wpt = (sizeof(T) + 7) / 8;
+            const uint32_t chunks = (uint32_t)std::max<size_t>(1, (g_.carry_cap * wpt + WB_COMMIT_CHUNK - 1) / WB_COMMIT_CHUNK);
+            const unsigned cgrid = (unsigned)std::min<size_t>(4096, std::max<size_t>(1, (runs_upper * chunks + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE)));
+            hipLaunchKernelGGL((wb_commit_kernel<T>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), states_.data(), runs_.data(), n_fire_.data(),
+                               win_off_.data(), work_.data(), carry_.data(), ctl_.data(), counters_.data(), g_, chunks);
+        }
         hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data());
         kernels += 10 + sorter_.kernels_per_sort(slot_bits_ + 1);
         return out;
