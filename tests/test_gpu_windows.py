@@ -353,3 +353,79 @@ def test_key_ffat_fuzz(ext, case):
                 lw += 1
                 n_exp += 1
         assert len(got) == n_exp
+
+
+# ---- huge runs: a key that owns thousands of tuples of a batch is spread over the chip (ffat_huge_gpu.hpp) -----------------
+
+def hot_stream(n, n_cold, hot_share, seed, ts_step=1):
+    """one hot key receives `hot_share` of the tuples, the rest goes to n_cold other keys"""
+    rng = np.random.default_rng(seed)
+    t, vals = make_stream(n, max(n_cold, 1), seed, ts_step=ts_step)
+    hot = rng.random(n) < hot_share
+    t[hot, 0] = 999_983
+    return t, vals
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,n_cold,share,win,slide,batch", [
+    (120_000, 3000, 0.4, 16, 4, 16384),     # the flagship geometry, zipf-like head
+    (150_000, 1, 0.5, 12, 4, 32768),        # two keys, both huge
+    (100_000, 200, 0.9, 7, 1, 8192),        # one-tuple panes: a window fires per tuple
+    (100_000, 50, 0.6, 1024, 128, 16384),   # long panes (128 tuples): few leaves per chunk
+    (90_000, 10, 0.7, 100, 100, 16384),     # tumbling
+    (90_000, 10, 0.7, 30, 90, 16384),       # hopping
+    (60_000, 5, 0.8, 63, 1, 4096),          # 63 panes per window: the widest the direct fold takes... 
+    (60_000, 5, 0.8, 200, 1, 4096),         # ... and beyond it: the wave-per-run kernel keeps these
+])
+def test_key_ffat_huge_runs_count_based(ext, n, n_cold, share, win, slide, batch, mode):
+    t, vals = hot_stream(n, n_cold, share, seed=n + win + mode)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, False, max(16, n_cold + 1), batch, 4 * batch, mode)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0
+    assert (ctr["huge_runs"] > 0) == (win // math.gcd(win, slide) <= 64), "the hot key's runs did not take the path they should"
+    got = unpack(res)
+    assert len(got) == len(res), "duplicate (key, window) results"
+    n_exp = 0
+    for key in np.unique(t[:, 0]):
+        m = t[:, 0] == key
+        v, ts = vals[m], t[m, 2]
+        lw = 0
+        while lw * slide < len(v):
+            w = v[lw * slide:lw * slide + win]
+            if len(w):
+                exp = w.sum() if mode == 0 else (w[-1] if mode == 1 else w[0])
+                assert got[(int(key), lw)][0] == pytest.approx(exp, abs=1e-9), (key, lw)
+                if mode == 0:
+                    assert got[(int(key), lw)][1] == int(ts[min(len(v), lw * slide + win) - 1]), (key, lw)
+            lw += 1
+            n_exp += 1
+    assert len(got) == n_exp
+
+
+@pytest.mark.parametrize("n,n_cold,share,win,slide,batch,ts_step", [
+    (120_000, 2000, 0.4, 400, 100, 16384, 1),        # many panes per batch
+    (120_000, 100, 0.5, 400_000, 100_000, 16384, 1), # less than one pane per batch: the run is one big reduction
+    (100_000, 3, 0.6, 64, 16, 8192, 5),              # time advances faster than the tuples: quanta nobody hits
+    (100_000, 3, 0.6, 5000, 5000, 8192, 1),          # tumbling
+])
+def test_key_ffat_huge_runs_time_based(ext, n, n_cold, share, win, slide, batch, ts_step):
+    t, vals = hot_stream(n, n_cold, share, seed=n + slide, ts_step=ts_step)
+    res, ctr = ext.key_ffat_run(t, win, slide, 0, True, max(16, n_cold + 1), batch, 1 << 19)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    assert ctr["huge_runs"] > 0
+    got = unpack(res)
+    exp = oracle_tb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, s in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9), k
+
+
+def test_key_ffat_huge_runs_with_disorder_fall_back(ext):
+    """a hot key whose tuples are not in timestamp order (delay 0: the late ones are dropped, by the same rules as a short run)"""
+    t, vals = hot_stream(80_000, 20, 0.7, seed=17)
+    rng = np.random.default_rng(3)
+    t[:, 2] = np.maximum(0, t[:, 2] + rng.integers(-400, 1, len(t)))
+    res_a, ctr_a = ext.key_ffat_run(t, 1000, 250, 0, True, 64, 16384, 1 << 18)
+    # same stream in batches too small for a huge run: the sequential rules decide alone
+    res_b, ctr_b = ext.key_ffat_run(t, 1000, 250, 0, True, 64, 1024, 1 << 18)
+    assert ctr_a["dropped"] == ctr_b["dropped"] and ctr_a["dropped"] > 0
+    assert unpack(res_a) == unpack(res_b)

@@ -247,6 +247,7 @@ static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::arra
     counters["dropped"] = c.dropped;
     counters["overflow"] = c.overflow;
     counters["skipped_windows"] = c.skipped_windows;
+    counters["huge_runs"] = c.huge_runs;
     counters["table_full"] = c.table_full;
     counters["kernels"] = kernels;
     counters["device_bytes"] = engine.device_bytes();
@@ -404,8 +405,9 @@ public:
         d["latency_mean_us"] = latency_->mean_us();
         d["latency_samples"] = latency_->count();
         d["threads"] = graph_.getNumThreads();
-        uint64_t dropped = 0, overflow = 0, skipped = 0, full = 0;
+        uint64_t dropped = 0, overflow = 0, skipped = 0, full = 0, huge = 0;
         for (auto& c : kff_->getDeviceCounters()) {
+            huge += c.huge_runs;
             dropped += c.dropped;
             overflow += c.overflow;
             skipped += c.skipped_windows;
@@ -415,6 +417,7 @@ public:
         d["overflow"] = overflow;
         d["skipped_windows"] = skipped;
         d["table_full"] = full;
+        d["huge_runs"] = huge;
         if (exchange_) exchange_stats(d, exchange_->stats(), exchange_->getOutputLanes());
         return d;
     }

@@ -1,0 +1,389 @@
+// Huge runs of the keyed FlatFAT engine: a key that owns thousands of tuples of a batch (a hot key of a skewed stream, or a
+// stream with a handful of keys) is spread over the whole chip instead of being folded by one wave.
+//
+// The per-key rules of key_ffat_gpu.hpp are sequential in the number of panes, but the combine is associative, so the run
+// is cut in chunks of 64 tuples that are reduced independently:
+//   1. ffat_huge_setup_kernel    one thread per huge run: its length (binary search in the sorted slots), where its chunks,
+//                                partial aggregates and pane leaves live in the scratch buffers, the state it starts from
+//   2. ffat_huge_chunks_kernel   one wave per chunk, all chunks of all runs at once: gather + lift + order-preserving segmented
+//                                wave scan by pane.  Panes that begin and end inside the chunk are final: they are written as
+//                                LEAVES of the run (a flat array of pane aggregates, the run's FlatFAT leaf level); the first
+//                                and the last segment of a chunk may continue in its neighbours: they are left as PARTIALS
+//   3. ffat_huge_fix_kernel      one wave per run: stitches the partials in order (a few per chunk), fills the panes no
+//                                tuple fell into (time-based windows), appends the panes to the key's tree in HBM, advances
+//                                the key's state and reserves room in the output batch for the windows the run fires
+//   4. ffat_huge_windows_kernel  one thread per fired window over the leaves (old panes of the key in front, new ones behind)
+// Used for count-based windows and for time-based windows without triggering delay whose run is in timestamp order and not
+// sparse in time; everything else (and windows of more than FFAT_HUGE_MAX_WIN panes) goes to the wave-per-run kernel, which
+// implements the full rules.  The engine switches these four launches on when a batch shows a huge run and off again after
+// a while without one (key_ffat_gpu.hpp), so streams without hot keys do not pay for them.
+//
+// Reference: the reference engine (wf/win_seqffat_gpu.hpp:369-396 + wf/flatfat_gpu.hpp:251-434) handles ONE key per replica
+// and rebuilds its tree level by level, one launch per level; it has no notion of a batch that mixes hot and cold keys.
+// (included by key_ffat_gpu.hpp, after the per-key rules it builds on)
+#pragma once
+#include "flatfat_gpu.hpp"
+#include "primitives.hpp"
+
+namespace wf {
+namespace gpu {
+
+constexpr uint32_t FFAT_HUGE_RUN = 2048;    // tuples of one key in one batch from which the run is spread over the chip
+constexpr uint32_t FFAT_HUGE_MAX_WIN = 64;  // panes per window up to which a fired window is folded directly from the leaves
+
+template <typename R>
+struct FFATPartial {
+    R val;
+    uint32_t pane;   // relative to the first pane the run can complete
+    uint32_t valid;
+};
+
+struct FFATHugeCtl {
+    uint32_t n_runs, total_chunks, pad0, pad1;
+};
+
+struct FFATHugeRun {
+    uint32_t head, len, slot, n_chunks;
+    uint32_t chunk_base;  // first chunk of the run in the batch-wide chunk numbering
+    uint32_t leaf_base;   // first leaf of the run in the scratch: win_panes - 1 old panes, then the panes of the run
+    uint32_t max_panes, pc0;
+    uint64_t P0, Lq, first_lwid;
+    uint32_t m, nf, out_base, fallback;
+};
+
+template <typename T, typename R>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_setup_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const FFATKeyState<R>* states,
+                           uint64_t pane_len, uint32_t is_tb, uint32_t win_panes, const uint32_t* huge_heads, const uint32_t* n_huge, FFATHugeRun* runs,
+                           FFATHugeCtl* ctl, uint32_t max_runs, uint32_t leaves_cap) {
+    const uint32_t n = hdr->count;
+    uint32_t nr = *n_huge;
+    if (nr > max_runs) nr = max_runs;
+    for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
+        FFATHugeRun hr{};
+        hr.head = huge_heads[r];
+        hr.slot = sslot[hr.head];
+        uint32_t lo = hr.head + FFAT_HUGE_RUN - 1, hi = n;  // sslot[lo] == slot (that is what made the run huge)
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (sslot[mid] == hr.slot)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        hr.len = lo + 1 - hr.head;
+        hr.n_chunks = (hr.len + WAVE - 1) / WAVE;
+        const FFATKeyState<R>& st = states[hr.slot];
+        hr.P0 = st.panes;
+        hr.first_lwid = st.next_lwid;
+        if (!is_tb) {
+            hr.pc0 = st.pcount;
+            hr.max_panes = (uint32_t)(((uint64_t)hr.pc0 + hr.len) / pane_len) + 1;
+        } else {
+            hr.Lq = st.last_quantum;
+            const uint64_t q0 = cf_ts(data[sidx[hr.head]]) / pane_len, q1 = cf_ts(data[sidx[hr.head + hr.len - 1]]) / pane_len;
+            // late tuples, disorder across the run, or a run that is sparse in time (more panes than tuples: most windows are
+            // empty): the sequential rules handle them
+            if (q0 < hr.Lq || q1 < q0 || q1 - hr.Lq > (uint64_t)hr.len + WAVE)
+                hr.fallback = 1;
+            else
+                hr.max_panes = (uint32_t)(q1 - hr.Lq) + 1;
+        }
+        runs[r] = hr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t chunks = 0, leaves = 0;
+        for (uint32_t r = 0; r < nr; r++) {
+            FFATHugeRun& hr = runs[r];
+            const uint32_t need = hr.fallback ? 0 : (win_panes - 1) + hr.max_panes;
+            if (leaves + need > leaves_cap) hr.fallback = 1;  // cannot happen with the sizes the engine allocates; stay safe
+            hr.chunk_base = chunks;
+            hr.leaf_base = leaves;
+            if (!hr.fallback) {
+                chunks += hr.n_chunks;
+                leaves += need;
+            } else {
+                hr.n_chunks = 0;
+            }
+        }
+        ctl->n_runs = nr;
+        ctl->total_chunks = chunks;
+    }
+}
+
+template <typename T, typename R, typename L, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_chunks_kernel(const T* data, const uint32_t* sidx, uint64_t pane_len, uint32_t is_tb, uint32_t win_panes, FFATHugeRun* runs,
+                            const FFATHugeCtl* ctl, FFATPartial<R>* parts, R* leaves, L lift, C comb) {
+    const uint32_t total = ctl->total_chunks, nr = ctl->n_runs;
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    const int lane = lane_id();
+    for (uint32_t u = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); u < total; u += waves_total) {
+        // the run this chunk belongs to: last run whose chunk_base <= u (runs without chunks share their successor's base)
+        uint32_t lo = 0, hi = nr;
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (runs[mid].chunk_base <= u)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        while (runs[lo].n_chunks == 0 && lo > 0) lo--;  // (fallback runs hold no chunk)
+        const FFATHugeRun hr = runs[lo];
+        const uint32_t c = u - hr.chunk_base;
+        const uint32_t pos = c * WAVE + (uint32_t)lane;
+        const bool ok = pos < hr.len;
+        const uint32_t cnt = hr.len - c * WAVE < (uint32_t)WAVE ? hr.len - c * WAVE : (uint32_t)WAVE;
+        R val{};
+        uint64_t pane = 0;
+        if (ok) {
+            const T t = data[sidx[hr.head + pos]];
+            val = ffat_lift<T, R, L>(t, lift);
+            pane = is_tb ? cf_ts(t) / pane_len - hr.Lq : ((uint64_t)hr.pc0 + pos) / pane_len;
+        }
+        const uint32_t lo32 = (uint32_t)(pane & 0xffffffffu), hi32 = (uint32_t)(pane >> 32);
+        const uint32_t plo = (uint32_t)__shfl_up((int)lo32, 1, WAVE), phi = (uint32_t)__shfl_up((int)hi32, 1, WAVE);
+        uint64_t prev = ((uint64_t)phi << 32) | plo;
+        if (is_tb) {
+            // panes must not decrease along the run (and never fall before the oldest open one: unsigned wrap-around)
+            if (lane == 0 && pos > 0 && ok) prev = cf_ts(data[sidx[hr.head + pos - 1]]) / pane_len - hr.Lq;
+            const bool bad = ok && ((pos > 0 && pane < prev) || pane >= (uint64_t)hr.max_panes);
+            if (__ballot(bad) != 0) {
+                if (lane == 0) atomicOr(&runs[lo].fallback, 1u);
+                continue;
+            }
+        }
+        const bool boundary = ok && (lane == 0 || prev != pane);
+        const unsigned long long bmask = __ballot(boundary);
+        const unsigned long long upto_me = bmask & (lanemask_lt() | (1ull << lane));
+        const int seg = __popcll(upto_me) - 1;
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int oseg = __shfl_up(seg, d, WAVE);
+            const bool take = ok && lane >= d && oseg == seg;
+            if (__ballot(take) == 0) break;
+            const R other = wave_shfl_up(val, d);
+            if (take) {
+                R tmp;
+                fat_combine(comb, other, val, tmp);
+                val = tmp;
+            }
+        }
+        const bool tail = ok && ((lane + 1 == (int)cnt) || ((bmask >> (lane + 1)) & 1ull));
+        const int n_segs = __popcll(bmask);
+        FFATPartial<R>* my_parts = parts + 2 * (size_t)u;
+        if (tail) {
+            if (seg == 0) {
+                my_parts[0].val = val;
+                my_parts[0].pane = (uint32_t)pane;
+                my_parts[0].valid = 1;
+            } else if (seg == n_segs - 1) {
+                my_parts[1].val = val;
+                my_parts[1].pane = (uint32_t)pane;
+                my_parts[1].valid = 1;
+            } else {
+                R v = val;
+                if (is_tb) v.setControlFields(cf_key(val), hr.Lq + pane, (hr.Lq + pane + 1) * pane_len - 1);
+                leaves[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)pane] = v;
+            }
+        }
+        if (lane == 0 && n_segs < 2) my_parts[1].valid = 0;
+        if (is_tb) {
+            // quanta between two segments of this chunk that received nothing: empty panes
+            const uint64_t gap = boundary && lane > 0 ? pane - prev - 1 : 0;
+            if (__ballot(gap != 0) != 0 && gap != 0) {
+                for (uint64_t q = prev + 1; q < pane; q++) {
+                    R e{};
+                    e.setControlFields(cf_key(val), hr.Lq + q, (hr.Lq + q + 1) * pane_len - 1);
+                    leaves[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)q] = e;
+                }
+            }
+        }
+    }
+}
+
+template <typename R, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
+                         const FFATHugeCtl* ctl, const FFATPartial<R>* parts, R* leaves, uint32_t* out_count, uint32_t* long_heads, uint32_t* n_long,
+                         const unsigned long long* table, FFATCounters* ctr, C comb) {
+    // (raw bytes: result types with default member initialisers cannot be declared __shared__)
+    __shared__ __align__(16) char s_raw[(BLOCK_THREADS / WAVE) * WAVE * sizeof(FFATPartial<R>)];
+    FFATPartial<R>* s_mine = reinterpret_cast<FFATPartial<R>*>(s_raw) + (size_t)wave_id() * WAVE;
+    const uint32_t nr = ctl->n_runs;
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    const int lane = lane_id();
+    const uint32_t W = g.win_panes;
+    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < nr; r += waves_total) {
+        FFATHugeRun hr = runs[r];
+        if (hr.fallback) {
+            if (lane == 0) long_heads[atomicAdd(n_long, 1u)] = hr.head;
+            continue;
+        }
+        FFATKeyState<R> st = states[hr.slot];
+        R* gtree = trees + (size_t)hr.slot * 2 * g.tree_cap;
+        R* lv = leaves + (size_t)hr.leaf_base + (W - 1);  // lv[p] = pane P0 + p
+        using key_t = decltype(cf_key(st.partial));
+        const key_t key = (key_t)table[hr.slot];
+        // the panes a window fired by this run can still need, in front of the new ones
+        for (uint32_t j = (uint32_t)lane; j + 1 < W; j += WAVE) {
+            const uint64_t back = (uint64_t)(W - 1 - j);  // pane P0 - back
+            if (hr.P0 >= back) lv[-(int64_t)back] = gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))];
+        }
+        // what was open before the run is the head of pane 0
+        bool c_has = false;
+        uint32_t c_pane = 0;
+        R c_val{};
+        R* acc = g.is_tb ? accs + (size_t)hr.slot * g.acc_cap : nullptr;
+        uint8_t* used = g.is_tb ? acc_used + (size_t)hr.slot * g.acc_cap : nullptr;
+        if (!g.is_tb) {
+            if (hr.pc0 > 0) {
+                c_has = true;
+                c_val = st.partial;
+            }
+        } else {
+            const uint32_t a = (uint32_t)(hr.Lq & (g.acc_cap - 1));
+            if (used[a]) {
+                c_has = true;
+                c_val = acc[a];
+            }
+        }
+        wave_sync_lds();
+        if (g.is_tb && lane == 0)
+            for (uint32_t a = 0; a < g.acc_cap; a++) used[a] = 0;
+        auto put_leaf = [&](uint32_t p, const R& v) {  // lane 0
+            R x = v;
+            if (g.is_tb) x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+            lv[p] = x;
+        };
+        // time-based: panes [from, to) received nothing (whole wave)
+        auto fill_gap = [&](uint32_t from, uint32_t to) {
+            for (uint32_t p = from + (uint32_t)lane; p < to; p += WAVE) {
+                R e{};
+                e.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+                lv[p] = e;
+            }
+        };
+        const uint32_t n_parts = 2 * hr.n_chunks;
+        for (uint32_t e0 = 0; e0 < n_parts; e0 += WAVE) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            if (e < n_parts) s_mine[lane] = parts[2 * (size_t)hr.chunk_base + e];
+            wave_sync_lds();
+            const uint32_t ne = n_parts - e0 < (uint32_t)WAVE ? n_parts - e0 : (uint32_t)WAVE;
+            // lane 0 stitches; the gaps it finds are filled by the whole wave afterwards (their bounds go through LDS-free
+            // registers of lane 0 and a broadcast)
+            for (uint32_t k = 0; k < ne; k++) {
+                uint32_t gap_from = 0, gap_to = 0;
+                if (lane == 0) {
+                    const FFATPartial<R>& pe = s_mine[k];
+                    if (pe.valid) {
+                        if (c_has && c_pane == pe.pane) {
+                            R tmp;
+                            fat_combine(comb, c_val, pe.val, tmp);
+                            c_val = tmp;
+                        } else {
+                            if (c_has) put_leaf(c_pane, c_val);
+                            // (the interior panes of a chunk lie between its two partials and were written by the chunk)
+                            if (g.is_tb) {
+                                const bool same_chunk = ((e0 + k) & 1u) != 0;  // second partial of its chunk
+                                const uint32_t lo_p = c_has ? c_pane + 1 : 0;
+                                if (!same_chunk && pe.pane > lo_p) {
+                                    gap_from = lo_p;
+                                    gap_to = pe.pane;
+                                }
+                            }
+                            c_has = true;
+                            c_pane = pe.pane;
+                            c_val = pe.val;
+                        }
+                    }
+                }
+                if (g.is_tb) {
+                    gap_from = (uint32_t)__shfl((int)gap_from, 0, WAVE);
+                    gap_to = (uint32_t)__shfl((int)gap_to, 0, WAVE);
+                    if (gap_to > gap_from) fill_gap(gap_from, gap_to);
+                }
+            }
+            wave_sync_lds();
+        }
+        // the last pane of the run: complete (count-based, when the run ends on a pane boundary) or left open
+        uint32_t m;
+        if (lane == 0) {
+            if (!g.is_tb) {
+                const uint64_t total = (uint64_t)hr.pc0 + hr.len;
+                m = (uint32_t)(total / g.pane_len);
+                const uint32_t rem = (uint32_t)(total % g.pane_len);
+                if (rem == 0) {
+                    put_leaf(c_pane, c_val);
+                    st.pcount = 0;
+                } else {
+                    st.partial = c_val;
+                    st.pcount = rem;
+                }
+            } else {
+                m = c_pane;  // quantum Lq + c_pane stays open
+                const uint64_t q1 = hr.Lq + c_pane;
+                const uint32_t a = (uint32_t)(q1 & (g.acc_cap - 1));
+                acc[a] = c_val;
+                used[a] = 1;
+                st.last_quantum = q1;
+                if (q1 + 1 > st.max_quantum) st.max_quantum = q1 + 1;
+            }
+            st.seen = 1;
+            st.panes = hr.P0 + m;
+            const uint64_t k_end = st.panes >= W ? (st.panes - W) / g.slide_panes + 1 : 0;
+            hr.nf = k_end > st.next_lwid ? (uint32_t)(k_end - st.next_lwid) : 0;
+            hr.first_lwid = st.next_lwid;
+            hr.out_base = hr.nf ? atomicAdd(out_count, hr.nf) : 0;
+            if (k_end > st.next_lwid) st.next_lwid = k_end;
+            hr.m = m;
+            runs[r] = hr;
+            states[hr.slot] = st;
+            atomicAdd(&ctr->huge_runs, 1u);
+        }
+        m = (uint32_t)__shfl((int)m, 0, WAVE);
+        wave_sync_lds();
+        // append the new panes to the key's tree (the newest tree_cap of them) and rebuild it
+        const uint64_t Pn = hr.P0 + m;
+        uint64_t lo = Pn > g.tree_cap ? Pn - g.tree_cap : 0;
+        if (lo < hr.P0) lo = hr.P0;
+        for (uint64_t idx = lo + (uint64_t)lane; idx < Pn; idx += WAVE) gtree[g.tree_cap + (uint32_t)(idx & (g.tree_cap - 1))] = lv[idx - hr.P0];
+        wave_sync_lds();
+        if (m > 0) fat_rebuild_wave(gtree, g.tree_cap, comb);
+        wave_sync_lds();
+    }
+}
+
+template <typename R, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_windows_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const R* leaves, R* out, FFATCounters* ctr,
+                             const unsigned long long* table, C comb) {
+    const uint32_t nr = ctl->n_runs;
+    const uint32_t W = g.win_panes;
+    for (uint32_t r = 0; r < nr; r++) {
+        const FFATHugeRun& hr = runs[r];
+        if (hr.fallback || hr.nf == 0) continue;
+        using key_t = decltype(cf_key(out[0]));
+        const key_t key = (key_t)table[hr.slot];
+        const R* lv = leaves + (size_t)hr.leaf_base + (W - 1);
+        for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < hr.nf; w += gridDim.x * blockDim.x) {
+            const uint64_t k = hr.first_lwid + w;
+            const int64_t first = (int64_t)(k * g.slide_panes) - (int64_t)hr.P0;  // >= -(W - 1)
+            R res = lv[first];
+            for (uint32_t p = 1; p < W; p++) {
+                R tmp;
+                fat_combine(comb, res, lv[first + (int64_t)p], tmp);
+                res = tmp;
+            }
+            res.setControlFields(key, k, cf_ts(res));
+            const uint32_t pos = hr.out_base + w;
+            if (pos < g.out_cap)
+                out[pos] = res;
+            else
+                atomicAdd(&ctr->overflow, 1u);
+        }
+    }
+}
+
+}  // namespace gpu
+}  // namespace wf

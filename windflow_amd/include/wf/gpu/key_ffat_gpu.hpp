@@ -63,6 +63,7 @@ struct FFATCounters {
     uint32_t overflow;         // results that did not fit the output batch
     uint32_t skipped_windows;  // TB: empty windows skipped by a time jump beyond the tree capacity
     uint32_t table_full;       // tuples whose key could not be inserted
+    uint32_t huge_runs;        // runs spread over the chip by the huge-run kernels (ffat_huge_gpu.hpp)
 };
 
 // where fired windows go.  GlobalEmit: one returning atomic per result (fine when a thread fires a
@@ -255,7 +256,8 @@ template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
                        R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
-                       uint32_t* n_long, L lift, C comb) {
+                       uint32_t* n_long, L lift, C comb, uint32_t huge_mode = 0, uint32_t huge_len = 0, uint32_t* huge_heads = nullptr,
+                       uint32_t* n_huge = nullptr, volatile uint32_t* huge_seen = nullptr, uint32_t batch_no = 0) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
@@ -265,7 +267,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             continue;
         }
         if (i + FFAT_LONG_RUN - 1 < n && sslot[i + FFAT_LONG_RUN - 1] == slot) {
-            long_heads[atomicAdd(n_long, 1u)] = i;
+            // huge_mode 1: a run long enough to be spread over the chip is only reported (the host then switches the
+            // huge-run kernels on for the batches that follow); 2: it is left to them (ffat_huge_gpu.hpp)
+            const bool huge = huge_mode != 0 && i + huge_len - 1 < n && sslot[i + huge_len - 1] == slot;
+            if (huge) *huge_seen = batch_no;
+            if (huge && huge_mode == 2)
+                huge_heads[atomicAdd(n_huge, 1u)] = i;
+            else
+                long_heads[atomicAdd(n_long, 1u)] = i;
             continue;
         }
         FFATKeyState<R> st = states[slot];
@@ -679,15 +688,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 
 // clamp the result count to the capacity and mirror it for the host
-__global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatile uint32_t* mirror, uint32_t* n_long = nullptr) {
+__global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatile uint32_t* mirror, uint32_t* n_long = nullptr,
+                                     uint32_t* n_huge = nullptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (n_long) *n_long = 0;  // ready for the next batch (same stream)
+        if (n_huge) *n_huge = 0;
         uint32_t c = out_hdr->count;
         if (c > cap) c = cap;
         out_hdr->count = c;
         *mirror = c;
     }
 }
+
+}  // namespace gpu
+}  // namespace wf
+#include "ffat_huge_gpu.hpp"
+namespace wf {
+namespace gpu {
 
 struct KeyOfTuple {
     template <typename T>
@@ -749,8 +766,21 @@ public:
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(FFATCounters), init.get()));
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
-        n_long_.resize(1);
-        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, sizeof(uint32_t), init.get()));
+        n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
+        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
+        // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones without a triggering delay, of few enough panes
+        huge_ok_ = (!g_.is_tb || delay == 0) && g_.win_panes <= FFAT_HUGE_MAX_WIN && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
+        if (huge_ok_) {
+            huge_max_runs_ = (uint32_t)(batch_cap_ / FFAT_HUGE_RUN + 1);
+            huge_leaves_cap_ = (uint32_t)(batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70));
+            huge_heads_.resize(huge_max_runs_);
+            huge_runs_.resize(huge_max_runs_);
+            huge_ctl_.resize(1);
+            huge_parts_.resize(2 * (batch_cap_ / WAVE + huge_max_runs_));
+            huge_leaves_.resize(huge_leaves_cap_);
+            WF_HIP_CHECK(hipHostMalloc((void**)&huge_seen_, 64, hipHostMallocDefault));
+            *huge_seen_ = 0;
+        }
         // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
         // (60 KB of dynamic LDS per block of 4 waves)
         long_layout_ = FFATLongLayout<R>::choose(g_, (60 * 1024) / (BLOCK_THREADS / WAVE));
@@ -764,6 +794,7 @@ public:
 
     ~KeyedFFATEngine() {
         for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+        if (huge_seen_) (void)hipHostFree((void*)huge_seen_);
     }
     KeyedFFATEngine(const KeyedFFATEngine&) = delete;
     KeyedFFATEngine& operator=(const KeyedFFATEngine&) = delete;
@@ -821,10 +852,33 @@ private:
                                table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
                                out->header(), (uint32_t*)nullptr);
             const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+            // huge runs: the four extra launches are only made while the stream shows such runs (the short-run kernel reports
+            // them through a pinned word; a run that shows up while they are off is handled by the wave-per-run kernel)
+            batch_no_++;
+            uint32_t huge_mode = 0;
+            if (huge_ok_ && !use_graphs_) {
+                const uint32_t seen = *huge_seen_;
+                huge_mode = (seen != 0 && batch_no_ - seen <= HUGE_LINGER_BATCHES) ? 2u : 1u;
+            }
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), lift_,
-                               comb_);
+                               comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_);
+            if (huge_mode == 2) {
+                hipLaunchKernelGGL((ffat_huge_setup_kernel<T, R>), dim3(1), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys,
+                                   sorted.vals, states_.data(), g_.pane_len, g_.is_tb, g_.win_panes, huge_heads_.data(), n_long_.data() + 1,
+                                   huge_runs_.data(), huge_ctl_.data(), huge_max_runs_, huge_leaves_cap_);
+                const unsigned cgrid = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (upper / WAVE + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
+                hipLaunchKernelGGL((ffat_huge_chunks_kernel<T, R, L, C>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, in->template data<T>(), sorted.vals,
+                                   g_.pane_len, g_.is_tb, g_.win_panes, huge_runs_.data(), huge_ctl_.data(), huge_parts_.data(), huge_leaves_.data(),
+                                   lift_, comb_);
+                const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
+                hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
+                                   acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts_.data(), huge_leaves_.data(),
+                                   out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
+                hipLaunchKernelGGL((ffat_huge_windows_kernel<R, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
+                                   huge_leaves_.data(), out->template data<R>(), counters_.data(), table_.data(), comb_);
+            }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
             hipLaunchKernelGGL((ffat_update_long_kernel<T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
@@ -832,7 +886,8 @@ private:
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), long_layout_,
                                lift_, comb_);
         }
-        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data());
+        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
+                           n_long_.data() + 1);
     }
 
 public:
@@ -882,6 +937,16 @@ private:
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;
     FFATLongLayout<R> long_layout_{0, 0, 0};
+    // huge runs
+    static constexpr uint32_t HUGE_LINGER_BATCHES = 256;  // batches without a huge run after which their kernels are switched off
+    bool huge_ok_ = false;
+    uint32_t huge_max_runs_ = 0, huge_leaves_cap_ = 0, batch_no_ = 0;
+    volatile uint32_t* huge_seen_ = nullptr;  // pinned: number of the last batch in which the device saw a huge run
+    DeviceBuffer<uint32_t> huge_heads_;
+    DeviceBuffer<FFATHugeRun> huge_runs_;
+    DeviceBuffer<FFATHugeCtl> huge_ctl_;
+    DeviceBuffer<FFATPartial<R>> huge_parts_;
+    DeviceBuffer<R> huge_leaves_;
     // hipGraph cache
     struct GraphKey {
         const void* in;
