@@ -111,9 +111,15 @@ struct KeySpace {
     int dist = KEYS_ROUNDROBIN;
     double zipf_alpha = 1.3;
     bool shared = false;  // every source draws from the same key set (a KeyBy is then needed in front of keyed operators)
-    // zipf: quantile table of the distribution, rank r has probability ~ 1 / (r+1)^alpha (2^20 quantiles, built once)
-    std::shared_ptr<std::vector<uint32_t>> quantiles;
-    static constexpr int QBITS = 20;
+    // zipf: rank r has probability ~ 1 / (r+1)^alpha.  Quantile table with 2^16 buckets of equal probability; a bucket holds the
+    // first rank that falls in it and how many ranks it spans: hot ranks own many buckets, the ranks of the tail share theirs and
+    // are drawn uniformly inside it.  (512 KB, cache resident: a generator thread must not stall on DRAM for every tuple; the
+    // mass of every bucket is exact, the shape inside a tail bucket is flattened.)
+    struct Bucket {
+        uint32_t first, span;
+    };
+    std::shared_ptr<std::vector<Bucket>> quantiles;
+    static constexpr int QBITS = 16;
     void prepare() {
         if (dist != KEYS_ZIPF || quantiles) return;
         const size_t n = n_keys, q = size_t(1) << QBITS;
@@ -123,14 +129,22 @@ struct KeySpace {
             acc += std::pow((double)(r + 1), -zipf_alpha);
             cdf[r] = (double)acc;
         }
-        auto tab = std::make_shared<std::vector<uint32_t>>(q);
+        auto tab = std::make_shared<std::vector<Bucket>>(q);
         size_t r = 0;
         for (size_t i = 0; i < q; i++) {
-            const double u = ((double)i + 0.5) / (double)q * (double)acc;
-            while (r + 1 < n && cdf[r] < u) r++;
-            (*tab)[i] = (uint32_t)r;
+            // ranks whose cumulative probability interval meets bucket i = [i, i+1) / q
+            const double lo = (double)i / (double)q * (double)acc, hi = (double)(i + 1) / (double)q * (double)acc;
+            while (r + 1 < n && cdf[r] <= lo) r++;
+            size_t e = r;
+            while (e + 1 < n && cdf[e] < hi) e++;
+            (*tab)[i] = Bucket{(uint32_t)r, (uint32_t)(e - r + 1)};
         }
         quantiles = tab;
+    }
+    // rank drawn by 64 random bits
+    static inline uint64_t zipf_rank(const Bucket* tab, uint64_t rnd) {
+        const Bucket b = tab[rnd >> (64 - QBITS)];
+        return b.span == 1 ? b.first : b.first + (uint64_t)(((rnd & 0xffffffffull) * b.span) >> 32);
     }
     static KeySpace make(size_t n_keys, int dist = KEYS_ROUNDROBIN, double alpha = 1.3, bool shared = false) {
         KeySpace k;
@@ -181,7 +195,7 @@ public:
         if (rng_ == 0) rng_ = 0x9E3779B97F4A7C15ull * (src + 1);
         uint64_t rng = rng_;
         const int dist = keys_.dist;
-        const uint32_t* quant = keys_.quantiles ? keys_.quantiles->data() : nullptr;
+        const KeySpace::Bucket* quant = keys_.quantiles ? keys_.quantiles->data() : nullptr;
         for (int64_t i = 0; i < take; i++, seq++) {
             uint64_t k, id;
             if (dist == KEYS_ROUNDROBIN) {
@@ -195,7 +209,7 @@ public:
                 rng ^= rng << 13;  // xorshift64
                 rng ^= rng >> 7;
                 rng ^= rng << 17;
-                k = dist == KEYS_UNIFORM ? (uint64_t)(((unsigned __int128)rng * nk) >> 64) : (uint64_t)quant[rng >> (64 - KeySpace::QBITS)];
+                k = dist == KEYS_UNIFORM ? (uint64_t)(((unsigned __int128)rng * nk) >> 64) : KeySpace::zipf_rank(quant, rng);
                 id = seq;
             }
             if (nt) {

@@ -344,13 +344,14 @@ public:
             // a round carries up to one batch per local lane and rank: the lane batches hold up to 2 * n_sources / lanes input batches
             wcfg.out_capacity = std::max<size_t>(2 * n_sources * batch_len / n_sinks_, batch_len);
         } else if (shared_keys) {
-            // every lane carries every key: device KeyBy (one partition kernel chain per batch) in front of the replicas
+            // every lane carries every key: device KeyBy in front of the replicas (the batches of all sources are packed by replica
+            // and merged: a replica receives batches of up to 2 * n_sources / replicas input batches)
             wcfg.lanes_are_key_disjoint = false;
-            n_sinks_ = agg_replicas ? agg_replicas : n_sources;
+            n_sinks_ = agg_replicas ? agg_replicas : std::min<size_t>(n_sources, 4);
             wcfg.max_keys = n_keys / n_sinks_;  // shared: n_keys is the whole key space
             wcfg.max_keys += wcfg.max_keys / 4 + 1024;
-            wcfg.out_capacity = 2 * batch_len;  // a hot key can send a replica more than its share of a batch
-            punct_expected_ = n_sinks_ * n_sources;  // every sub-batch of a lane's punctuated batch carries the punctuation
+            wcfg.out_capacity = std::max<size_t>(2 * n_sources * batch_len / n_sinks_, 2 * batch_len);
+            if (n_sinks_ == 1) punct_expected_ = n_sources;  // no KeyBy in front of a single replica: it sees every lane's punctuation
         }
         if (punct_expected_ == 0) punct_expected_ = n_sinks_;
         kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg));
@@ -567,9 +568,8 @@ public:
     std::string dot() { return graph_.get_DOTGraph(); }
 
 private:
-    // every batch that carries a punctuation reaches exactly one sink when the lanes map 1:1; behind the device KeyBy every
-    // sub-batch of a punctuated batch carries it, so each sink sees one per source
-    size_t punct_expected() const { return (n_sinks_ == n_sources_ && keyby_free_) ? n_sinks_ : n_sinks_ * n_sources_; }
+    // a step's punctuation reaches every sink once: lanes map 1:1, or the device KeyBy merges the punctuations of the sources
+    size_t punct_expected() const { return (n_sinks_ == 1 && n_sources_ > 1) ? n_sources_ : n_sinks_; }
     size_t n_sources_, n_sinks_;
     bool keyby_free_ = true;
     std::unique_ptr<wfbench::StepGate[]> gates_;
@@ -760,13 +760,13 @@ public:
             mp->add(*filter_[0]);
             mp->chain(*join_[0]);
         }
-        // a lane's step punctuation reaches the aggregation once per branch; the device KeyBy copies it to every replica
-        punct_expected_ = n_sinks_ * n_sources * branches;
+        // the device KeyBy / the exchange merge the punctuations of a step into one per aggregation replica; a single replica
+        // without an exchange in front is fed by every lane directly and sees the punctuation of each
+        punct_expected_ = (transport || n_sinks_ > 1) ? n_sinks_ : n_sources * branches;
         if (transport) {
             exchange_ = ExchangeGPU_Builder<ysb::Joined>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources * branches)
                             .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
             mp->add(*exchange_);
-            punct_expected_ = n_sinks_;  // the exchange merges the punctuations of a step into one per lane
         }
         agg_ = KeyFFATGPU_Builder(ysb::CountLift(), ysb::CountCombine()).withTBWindows(us(ysb::WINDOW_US), us(ysb::WINDOW_US), us(delay_us))
                    .withName("ysb_kff_gpu").withParallelism(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).withMaxKeys(256)

@@ -51,6 +51,10 @@ struct StageSpec {
     // ordering node to put in front of each replica for this mode (nullptr: none)
     std::function<rt::Node*(Mode)> make_ordering;
     bool internal = false;  // fed by the previous stage of the same operator
+    // Instead of `replicas`: the stage has exactly one node per upstream endpoint, built (not adopted) by this factory
+    // and FUSED onto its endpoint (node i of n) - work that belongs to the producer's thread, such as packing a batch
+    // by destination before it is handed to an exchange.
+    std::function<rt::Node*(size_t i, size_t n)> per_producer;
 };
 
 // What flows on the edge leaving an operator: individual heap tuples, batches in

@@ -1,0 +1,674 @@
+// Nodes of Exchange_GPU (dist/exchange_gpu.hpp) and of the device KeyBy in front of keyed GPU operators.
+//
+// Exchange_GPU: KeyBy across GPUs.  Every rank (process or thread owning one GPU)
+// places one Exchange_GPU in its MultiPipe; batches entering it are partitioned by
+// key on the device and re-distributed with one all-to-all per round, so that a key
+// is only ever seen by the rank that owns it - and, inside that rank, by the lane
+// that owns it: the exchange delivers `lanes` key-disjoint streams, one per replica
+// of the keyed operator behind it (Key_FFAT_GPU, Key_Farm_GPU, keyed Map_GPU ... built
+// with withKeyDisjointLanes()), which then run unchanged on purely local state and
+// need no second partitioning pass.  owner rank = bits 48-63 of mix64(key) mod world,
+// lane = bits 24-47 mod lanes (gpu/keyby_gpu.hpp).
+//
+// No counterpart in the reference (single process, no inter-GPU traffic, SURVEY.md
+// §2.6); this is the piece that turns "N replicas on N GPUs" into a scalable
+// one-process-per-GPU deployment over xGMI.
+//
+//   lanes (stage 1, one thread per producer lane): ship the batch to the device if needed and pack it by destination
+//           (rank, lane): ONE slab ordered by destination + the destination offsets in pinned memory.  Nothing waits:
+//           the bundle carries the event of the pack kernels.
+//   endpoint (stage 2, one thread per rank) runs ROUNDS, several in flight:
+//           stage     every packed slab that is ready (up to one per local lane) joins the next round: their per-destination
+//                     segments are merged into one send slab ordered by destination (one segmented-copy kernel), so a round
+//                     under load carries `local lanes` batches per rank in ONE slice per peer - few, fat transfers per
+//                     xGMI link instead of many thin ones - while a lone batch goes out as it is (no merge, low latency).
+//           publish   the per-destination counts of the round become the rank's row on the control board
+//                     (dist/transport.hpp).  A rank without input answers a round that some other rank has opened with an
+//                     empty row at once; nobody idles on a timer.
+//           collect   once every rank's row of the oldest open round is there, the sizes of the all-to-all-v are known:
+//                     the peers' chunks (all the lanes of this rank, contiguous in their send slabs) land back to back in
+//                     a staging slab, one segmented-copy kernel lays them out as batches per lane (per-key order = round,
+//                     source rank, position: FIFO per producer is preserved; a lane that receives more than a lane batch
+//                     holds - a hot key - gets several), the lane batches go downstream with their counts known on the
+//                     host.  The host never waits for the transfer.
+//           release   a send slab returns to its pool when the transport says the peers are done with it.
+//   With one rank there is nothing to exchange: the endpoint merges the ready packed slabs straight into lane batches
+//   (the device KeyBy, coalescing the batches of all local lanes).
+//   Step punctuations (header.reserved[0], see Batch_Source) are delivered downstream once every lane of every rank has
+//   reported them; the forwarded watermark is the minimum over the ranks still producing; at end of stream a rank keeps
+//   answering rounds until every rank is done and a round moved nothing.
+//
+// The same two stages, without a transport, are the KeyBy INSIDE a GPU (device_keyby_stages below): keyed GPU operators
+// whose input lanes are not key-disjoint put them in front of their replicas - every producer packs its batches by lane,
+// one endpoint thread merges the packed slabs of all producers into one batch per replica.
+#pragma once
+#include <cstddef>
+#include <deque>
+#include <map>
+#include <unordered_map>
+
+#include "../gpu/batch_ops.hpp"
+#include "../gpu/keyby_gpu.hpp"
+#include "control_board.hpp"
+
+namespace wf {
+
+struct ExchangeConfig {
+    size_t local_lanes = 0;        // producers feeding this exchange on this rank (punctuations to wait for per step); 0: as many as there are
+    size_t out_lanes = 1;          // key-disjoint streams delivered downstream (= replicas of the keyed operator behind)
+    uint64_t idle_round_us = 2000; // with no input and nobody else asking, still open a round this often (keeps watermarks moving)
+    size_t max_batches_per_round = 0;  // input batches merged into one round (0: one per local lane, at most 16)
+    // a round leaves when it is full (max_batches_per_round), when another rank is waiting for this one, or when its oldest
+    // batch has waited this long: under load the rounds are fat (few large transfers and kernels), a lone batch is delayed by
+    // at most this much
+    uint64_t linger_us = 300;
+};
+
+// counters of one rank's endpoint, readable after the run (Exchange_GPU::stats())
+struct ExchangeStats {
+    uint64_t rounds = 0, empty_rounds = 0;
+    uint64_t bundles = 0;        // input batches that went into the rounds (bundles / rounds = how fat the rounds were)
+    uint64_t lane_batches = 0;   // batches delivered downstream
+    uint64_t tuples_sent = 0, tuples_received = 0, bytes_received = 0;
+    uint64_t max_link_bytes_per_round = 0;  // xGMI is point to point: a round is bound by its busiest link
+    uint64_t start_us = 0, elapsed_us = 0;
+};
+
+// What a partition lane hands to the rank's endpoint
+struct ExchangeBundle {
+    uint64_t arrived_us = 0;                // when the endpoint got it
+    gpu::Batch* packed = nullptr;           // the batch grouped by destination (rank, lane)
+    volatile uint32_t* offsets = nullptr;   // pinned: world * lanes + 1 offsets into `packed`, valid once packed->ready has fired
+    gpu::Batch* passthrough = nullptr;      // one rank, one lane: the batch itself
+    gpu::BatchHeader hdr{};
+    size_t capacity = 0;
+};
+
+namespace gpu {
+// Segmented copy: segment y of the table is copied by the blocks (*, y); the first n_hdrs rows also write a batch header.
+// The table lives in pinned host memory (read over the bus once per block: a few KB per launch, no staging copy).
+struct SegCopy {
+    const void* src;
+    void* dst;
+    uint64_t count;  // tuples
+};
+struct HdrWrite {
+    BatchHeader value;
+    BatchHeader* dst;
+    uint64_t pad[7];
+};
+static_assert(sizeof(HdrWrite) == 128, "HdrWrite layout");
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS) segcopy_kernel(const SegCopy* segs, uint32_t n_segs, const HdrWrite* hdrs, uint32_t n_hdrs) {
+    using W = std::conditional_t<sizeof(T) % 8 == 0 && alignof(T) % 8 == 0, uint64_t,
+                                 std::conditional_t<sizeof(T) % 4 == 0 && alignof(T) % 4 == 0, uint32_t, unsigned char>>;
+    const uint32_t y = blockIdx.y;
+    if (y < n_hdrs && blockIdx.x == 0 && threadIdx.x < sizeof(BatchHeader) / 8)
+        reinterpret_cast<uint64_t*>(hdrs[y].dst)[threadIdx.x] = reinterpret_cast<const uint64_t*>(&hdrs[y].value)[threadIdx.x];
+    if (y >= n_segs) return;
+    const SegCopy sc = segs[y];
+    const size_t words = (size_t)sc.count * (sizeof(T) / sizeof(W));
+    const W* __restrict__ src = static_cast<const W*>(sc.src);
+    W* __restrict__ dst = static_cast<W*>(sc.dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ring of pinned tables for segcopy launches; a slot is reused once the kernel that read it has completed
+class SegTables {
+public:
+    explicit SegTables(size_t slots = 16) : slots_(slots) {}
+    ~SegTables() {
+        for (Slot& s : slots_)
+            if (s.mem) (void)hipHostFree(s.mem);
+    }
+    std::vector<SegCopy> segs;
+    std::vector<HdrWrite> hdrs;
+    void clear() {
+        segs.clear();
+        hdrs.clear();
+    }
+    // copies of `segs` (and header writes of `hdrs`) enqueued on s
+    template <typename T>
+    void launch(hipStream_t s) {
+        if (segs.empty() && hdrs.empty()) return;
+        Slot& slot = slots_[next_];
+        next_ = (next_ + 1) % slots_.size();
+        slot.ev.host_sync();
+        const size_t hb = hdrs.size() * sizeof(HdrWrite), sb = segs.size() * sizeof(SegCopy);
+        if (slot.bytes < hb + sb) {
+            if (slot.mem) WF_HIP_CHECK(hipHostFree(slot.mem));
+            slot.bytes = std::max<size_t>(2 * (hb + sb), 8192);
+            WF_HIP_CHECK(hipHostMalloc((void**)&slot.mem, slot.bytes, hipHostMallocDefault));
+        }
+        if (hb) std::memcpy(slot.mem, hdrs.data(), hb);
+        if (sb) std::memcpy(slot.mem + hb, segs.data(), sb);
+        uint64_t longest = 0;
+        for (const SegCopy& c : segs) longest = std::max(longest, c.count);
+        const size_t words = longest * ((sizeof(T) + 7) / 8);
+        const unsigned gx = (unsigned)std::min<size_t>(128, std::max<size_t>(1, (words + 8 * BLOCK_THREADS - 1) / (8 * BLOCK_THREADS)));
+        const unsigned gy = (unsigned)std::max(segs.size(), hdrs.size());
+        hipLaunchKernelGGL((segcopy_kernel<T>), dim3(gx, gy), dim3(BLOCK_THREADS), 0, s, reinterpret_cast<const SegCopy*>(slot.mem + hb),
+                           (uint32_t)segs.size(), reinterpret_cast<const HdrWrite*>(slot.mem), (uint32_t)hdrs.size());
+        WF_HIP_CHECK(hipGetLastError());
+        slot.ev.record(s);
+    }
+
+private:
+    struct Slot {
+        char* mem = nullptr;
+        size_t bytes = 0;
+        Event ev;
+    };
+    std::vector<Slot> slots_;
+    size_t next_ = 0;
+};
+}  // namespace gpu
+
+// ---- stage 1: partition lanes (parallel) ------------------------------------------------------
+template <typename tuple_t>
+class ExchangePart_Node : public GPU_Replica<tuple_t> {
+public:
+    ExchangePart_Node(int world, size_t out_lanes, GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx,
+                      meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub)), world_(world), lanes_(out_lanes) {}
+    ~ExchangePart_Node() override {
+        for (auto& kv : mirrors_) (void)hipHostFree((void*)kv.second);
+    }
+
+protected:
+    void gpu_init() override {
+        // a packed slab is held until its round has been merged (or, for a lone batch, until the peers have read it)
+        const size_t slabs = std::max<size_t>(3, this->cfg_.pool_slabs) + (world_ > 1 ? dist::ControlBoard::DEPTH : 2);
+        if (world_ > 1 || lanes_ > 1) part_.reset(new gpu::BatchPartitioner<tuple_t>(1, this->cfg_.gpu_id, slabs));
+    }
+    void process_device(gpu::Batch* d) override {
+        gpu::TraceRange trace("wf:exchange_partition");
+        auto* b = new ExchangeBundle();
+        b->hdr = d->host_hdr;
+        b->capacity = d->capacity;
+        hipStream_t s = this->stream();
+        if (part_) {
+            // the offsets mirror belongs to the slab the pack writes to: it is reused exactly when the slab is
+            b->packed = part_->partition_packed(d, (size_t)world_, lanes_, [this](gpu::Batch* slab) { return mirror_of(slab); }, s, this->num_kernels_);
+            b->offsets = mirror_of(b->packed);
+            this->release_input(d);
+            b->packed->ready.record(s);
+        } else {
+            d->ready.record(s);
+            b->passthrough = d;
+        }
+        this->emit(b);
+    }
+
+private:
+    volatile uint32_t* mirror_of(gpu::Batch* slab) {
+        auto it = mirrors_.find(slab);
+        if (it != mirrors_.end()) return it->second;
+        uint32_t* m = nullptr;
+        WF_HIP_CHECK(hipHostMalloc((void**)&m, (dist::MAX_WORLD * dist::MAX_LANES + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        mirrors_[slab] = m;
+        return m;
+    }
+    int world_;
+    size_t lanes_;
+    std::unique_ptr<gpu::BatchPartitioner<tuple_t>> part_;
+    std::unordered_map<gpu::Batch*, volatile uint32_t*> mirrors_;
+};
+
+// ---- stage 2: the rank's endpoint on the fabric (one thread) -------------------------------------
+template <typename tuple_t>
+class ExchangeEndpoint_Node : public Replica_Base {
+public:
+    ExchangeEndpoint_Node(std::shared_ptr<dist::Transport> tr, ExchangeConfig xcfg, GPUConfig cfg, std::string name, meta::closing_func_t closing,
+                          std::shared_ptr<StatsHub> hub, std::shared_ptr<ExchangeStats> xstats, std::shared_ptr<size_t> n_producers = nullptr)
+        : Replica_Base(std::move(name), 1, 0, std::move(closing), std::move(hub), false, true), tr_(std::move(tr)), xcfg_(xcfg), cfg_(cfg),
+          xstats_(std::move(xstats)), n_producers_(std::move(n_producers)) {
+        if (!xstats_) xstats_ = std::make_shared<ExchangeStats>();
+        if (world() > dist::MAX_WORLD) gpu::failwith("Exchange_GPU: world size above MAX_WORLD");
+        if (xcfg_.out_lanes == 0 || xcfg_.out_lanes > (size_t)dist::MAX_LANES) gpu::failwith("Exchange_GPU: between 1 and 16 output lanes");
+        cfg_.gpu_id = cfg.device_for(0);
+    }
+    void svc_init() override {
+        Replica_Base::svc_init();
+        // the producers are known once the graph is wired
+        if (xcfg_.local_lanes == 0) xcfg_.local_lanes = (n_producers_ && *n_producers_ > 0) ? *n_producers_ : 1;
+        group_ = std::min<size_t>(xcfg_.local_lanes, MAX_GROUP);
+        if (xcfg_.max_batches_per_round != 0) group_ = std::min(group_, xcfg_.max_batches_per_round);
+        WF_HIP_CHECK(hipSetDevice(cfg_.gpu_id));
+        stream_.reset(new gpu::Stream());
+        tables_.reset(new gpu::SegTables());
+        last_round_us_ = start_us_ = xstats_->start_us = current_time_usecs();
+    }
+    void svc(void* msg, int) override {
+        auto* b = static_cast<ExchangeBundle*>(msg);
+        b->arrived_us = current_time_usecs();
+        pending_.push_back(b);
+        pump();
+    }
+    bool wants_idle() const override { return true; }
+    void on_idle() override {
+        if (!finished_) pump();
+    }
+    void flush() override {
+        // end of my stream: keep answering rounds until everybody is done
+        done_ = true;
+        if (!stream_) return;  // never started
+        while (!finished_) {
+            if (!pump()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        // whatever this rank still reads from the peers' buffers completes here, so that they can finish too
+        if (tr_) tr_->quiesce(stream_->get());
+        while (!sent_.empty()) {
+            if (!release_sent()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    void svc_end() override {
+        if (stream_) stream_->sync();
+        tables_.reset();
+        if (xstats_) xstats_->elapsed_us = current_time_usecs() - start_us_;
+        Replica_Base::svc_end();
+    }
+
+protected:
+    void finalize_stats(Stats_Record& s) override { s.num_kernels = xstats_ ? xstats_->rounds : 0; }
+
+private:
+    int world() const { return tr_ ? tr_->world() : 1; }  // no transport: the KeyBy inside one GPU
+    int rank() const { return tr_ ? tr_->rank() : 0; }
+    static constexpr size_t MAX_GROUP = 16;                            // input batches merged into one round
+    static constexpr uint64_t WINDOW = dist::ControlBoard::DEPTH - 2;  // rounds published but not yet collected
+    using src_list_t = std::vector<std::pair<const tuple_t*, size_t>>;
+
+    // a round prepared for publication: its row and the buffer the peers will read
+    struct Staged {
+        dist::ControlRow row{};
+        gpu::Batch* buf = nullptr;
+        std::unique_ptr<gpu::Event> merged;  // the merge kernel (pull transports publish only once the buffer is complete)
+    };
+
+    // ready bundles at the head of the queue, at most group_.  Unless `now`, a round that is not full yet waits for more
+    // batches until its oldest one has lingered long enough.
+    size_t take_ready(std::vector<std::unique_ptr<ExchangeBundle>>& out, bool now) {
+        size_t ready = 0;
+        while (ready < group_ && ready < pending_.size() && pending_[ready]->packed->ready.done()) ready++;
+        if (ready == 0) return 0;
+        if (ready < group_ && !now && !done_ && current_time_usecs() - pending_.front()->arrived_us < xcfg_.linger_us) return 0;
+        for (size_t i = 0; i < ready; i++) {
+            out.emplace_back(pending_.front());
+            pending_.pop_front();
+        }
+        return ready;
+    }
+
+    bool stage_round(bool now) {
+        std::vector<std::unique_ptr<ExchangeBundle>> take;
+        if (take_ready(take, now) == 0) return false;
+        const size_t D = (size_t)world() * xcfg_.out_lanes;
+        hipStream_t s = stream_->get();
+        staged_.emplace_back();
+        Staged& st = staged_.back();
+        for (auto& b : take) {
+            my_cap_ = std::max(my_cap_, b->capacity);
+            if (b->hdr.reserved[0] != 0) note_local_punctuation(b->hdr.reserved[0]);
+            for (size_t d = 0; d < D; d++) st.row.counts[d] += b->offsets[d + 1] - b->offsets[d];
+            st.row.watermark = std::max(st.row.watermark, b->hdr.watermark);
+            if (b->hdr.created_ns != 0) st.row.created_ns = st.row.created_ns == 0 ? b->hdr.created_ns : std::min(st.row.created_ns, b->hdr.created_ns);
+        }
+        if (take.size() == 1) {
+            st.buf = take[0]->packed;  // a lone batch goes out as it is
+        } else {
+            st.buf = acquire(send_pool_, send_cap_, group_ * my_cap_, dist::ControlBoard::DEPTH + 4);
+            tables_->clear();
+            size_t run = 0;
+            for (size_t d = 0; d < D; d++)
+                for (auto& b : take) {
+                    const size_t lo = b->offsets[d], c = b->offsets[d + 1] - lo;
+                    if (c == 0) continue;
+                    tables_->segs.push_back({b->packed->template data<tuple_t>() + lo, st.buf->template data<tuple_t>() + run, c});
+                    run += c;
+                }
+            tables_->template launch<tuple_t>(s);
+            for (auto& b : take) b->packed->release(s);
+            st.merged.reset(new gpu::Event());
+            st.merged->record(s);
+        }
+        st.row.step = local_step_done_;
+        st.row.capacity = my_cap_;
+        tr_->describe_send(st.buf->slab, st.buf->template data<tuple_t>(), st.row);
+        xstats_->bundles += take.size();
+        return true;
+    }
+
+    // one step of the state machine; true if anything moved
+    bool pump() {
+        if (world() == 1) return pump_single();
+        bool progress = false;
+        dist::ControlBoard& board = tr_->board();
+        // publish
+        // (a round's slot on the board and in the transport is reused DEPTH rounds later: not before its send buffers are back)
+        while (pub_ - col_ < WINDOW && board.can_publish(pub_) && (sent_.empty() || sent_.front().first + dist::ControlBoard::DEPTH > pub_)) {
+            // a peer that has opened this round is waiting for this rank: answer with what is there
+            if (staged_.size() < 2 && stage_round(board.anyone_published(pub_))) progress = true;
+            dist::ControlRow row{};
+            gpu::Batch* buf = nullptr;
+            if (!staged_.empty()) {
+                Staged& st = staged_.front();
+                if (tr_->pulls() && st.merged && !st.merged->done()) break;  // the peers would read a half-written buffer
+                row = st.row;
+                buf = st.buf;
+                staged_.pop_front();
+            } else {
+                if (!board.anyone_published(pub_) && current_time_usecs() - last_round_us_ < xcfg_.idle_round_us)
+                    break;  // nothing to say yet, nobody is waiting for this rank, and the last round is recent
+                row.step = local_step_done_;
+                row.capacity = my_cap_;
+            }
+            row.done = (done_ && pending_.empty() && staged_.empty()) ? 1 : 0;
+            board.publish(pub_, row);
+            open_.push_back(buf);
+            pub_++;
+            last_round_us_ = current_time_usecs();
+            progress = true;
+        }
+        // collect
+        dist::ControlRow rows[dist::MAX_WORLD];
+        while (col_ < pub_ && board.try_collect(col_, rows)) {
+            gpu::Batch* buf = open_.front();
+            open_.pop_front();
+            run_round(col_, rows, buf);
+            col_++;
+            progress = true;
+        }
+        if (release_sent()) progress = true;
+        return progress;
+    }
+
+    void run_round(uint64_t round, const dist::ControlRow* rows, gpu::Batch* buf) {
+        gpu::TraceRange trace("wf:exchange_round");
+        const int world = tr_->world(), me = tr_->rank();
+        const size_t L = xcfg_.out_lanes;
+        hipStream_t s = stream_->get();
+        // what I receive: chunk[r] = all my lanes from rank r, contiguous in r's send buffer
+        size_t chunk[dist::MAX_WORLD], total = 0;
+        bool all_done = true, any_traffic = false;
+        uint64_t min_step = UINT64_MAX, created = 0;
+        dist::PeerSlices sl;
+        for (int r = 0; r < world; r++) {
+            const dist::ControlRow& row = rows[r];
+            chunk[r] = 0;
+            size_t before = 0;
+            for (size_t d = 0; d < (size_t)world * L; d++) {
+                any_traffic = any_traffic || row.counts[d] != 0;
+                if (d < (size_t)me * L) before += row.counts[d];
+            }
+            for (size_t l = 0; l < L; l++) chunk[r] += row.counts[(size_t)me * L + l];
+            sl.pull_offset[r] = before * sizeof(tuple_t);
+            total += chunk[r];
+            all_done = all_done && row.done != 0;
+            min_step = std::min(min_step, row.step);
+            rank_wm_[r] = std::max(rank_wm_[r], row.watermark);
+            rank_done_[r] = row.done != 0;
+            cap_ = std::max<size_t>(cap_, (size_t)row.capacity);
+            if (row.created_ns != 0 && chunk[r] > 0) created = created == 0 ? row.created_ns : std::min(created, row.created_ns);
+        }
+        // what I forward is the LOW watermark: the minimum over the ranks still producing
+        uint64_t wm = UINT64_MAX;
+        for (int r = 0; r < world; r++)
+            if (!rank_done_[r]) wm = std::min(wm, rank_wm_[r]);
+        if (wm == UINT64_MAX)
+            for (int r = 0; r < world; r++) wm = (r == 0) ? rank_wm_[r] : std::max(wm, rank_wm_[r]);
+        const uint64_t step_out = take_global_step(min_step);
+        gpu::Batch* stage = nullptr;
+        if (any_traffic) {
+            if (total > 0) {
+                // the staging slab grows with the traffic (a rank that owns the hot keys receives more than its share)
+                size_t want = std::max<size_t>(2 * group_ * std::max<size_t>(cap_, 1), 1);
+                while (want < total) want *= 2;
+                stage = acquire(stage_pool_, stage_cap_, want, cfg_.pool_slabs + 2);
+            }
+            size_t off = 0, mine_before = 0;
+            uint64_t sent = 0;
+            for (int p = 0; p < world; p++) {
+                size_t to_p = 0;
+                for (size_t l = 0; l < L; l++) to_p += rows[me].counts[(size_t)p * L + l];
+                if (to_p > 0) {
+                    sl.send[p] = buf->template data<tuple_t>() + mine_before;
+                    sl.send_bytes[p] = to_p * sizeof(tuple_t);
+                    sent += to_p;
+                }
+                mine_before += to_p;
+                if (chunk[p] > 0) {
+                    sl.recv[p] = stage->template data<tuple_t>() + off;
+                    sl.recv_bytes[p] = chunk[p] * sizeof(tuple_t);
+                    off += chunk[p];
+                }
+                if (p != me) xstats_->max_link_bytes_per_round = std::max<uint64_t>(xstats_->max_link_bytes_per_round, std::max(sl.send_bytes[p], sl.recv_bytes[p]));
+            }
+            xstats_->tuples_sent += sent;
+            xstats_->tuples_received += total;
+            xstats_->bytes_received += total * sizeof(tuple_t);
+        } else {
+            xstats_->empty_rounds++;
+        }
+        // every rank calls exchange() every round, in round order (the collectives of a communicator must line up)
+        tr_->exchange(round, sl, rows, s);
+        sent_.push_back({round, buf});
+        if (total > 0 || step_out != 0) {
+            src_list_t lane_src[dist::MAX_LANES];
+            size_t src = 0;
+            for (int r = 0; r < world; r++)
+                for (size_t l = 0; l < L; l++) {
+                    const size_t c = rows[r].counts[(size_t)me * L + l];
+                    if (c > 0) lane_src[l].push_back({stage->template data<tuple_t>() + src, c});
+                    src += c;
+                }
+            emit_lanes(lane_src, wm, created, step_out, s);
+        }
+        if (stage != nullptr) stage->release(s);
+        xstats_->rounds++;
+        if (all_done && !any_traffic) finished_ = true;
+    }
+
+    // lane_src[l]: the pieces of lane l's stream in delivery order.  They become batches of at most lane_cap_ tuples; a step
+    // punctuation rides on the last batch of every lane (an empty one if the lane received nothing).
+    void emit_lanes(src_list_t* lane_src, uint64_t wm, uint64_t created, uint64_t step_out, hipStream_t s) {
+        const size_t L = xcfg_.out_lanes;
+        if (lane_cap_ == 0) {
+            // fixed from here on: the operators behind size their buffers from the first batch they see
+            const size_t cap = std::max<size_t>(std::max(cap_, my_cap_), 1);
+            lane_cap_ = std::max(cap, (2 * group_ * cap + L - 1) / L);
+            lane_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(tuple_t), lane_cap_, std::max<size_t>(cfg_.pool_slabs, 3) * L));
+        }
+        tables_->clear();
+        std::vector<std::pair<gpu::Batch*, size_t>> outs;
+        size_t total = 0;
+        for (size_t l = 0; l < L; l++) {
+            size_t lane_total = 0;
+            for (auto& pc : lane_src[l]) lane_total += pc.second;
+            if (lane_total == 0 && step_out == 0) continue;
+            total += lane_total;
+            size_t piece = 0, piece_off = 0, left = lane_total;
+            do {
+                const size_t n = std::min(left, lane_cap_);
+                gpu::Batch* out = lane_pool_->acquire(s);
+                out->host_hdr = gpu::BatchHeader{};
+                out->host_hdr.count = (uint32_t)n;
+                out->host_hdr.source_id = (uint32_t)rank();
+                out->host_hdr.watermark = wm;
+                out->host_hdr.created_ns = created;
+                out->host_hdr.first_seq = seq_;
+                out->host_hdr.reserved[0] = (left == n) ? step_out : 0;
+                out->count_on_host = true;
+                gpu::HdrWrite hw{};
+                hw.value = out->host_hdr;
+                hw.dst = out->header();
+                tables_->hdrs.push_back(hw);
+                size_t fill = 0;
+                while (fill < n) {
+                    const size_t c = std::min(n - fill, lane_src[l][piece].second - piece_off);
+                    tables_->segs.push_back({lane_src[l][piece].first + piece_off, out->template data<tuple_t>() + fill, c});
+                    fill += c;
+                    piece_off += c;
+                    if (piece_off == lane_src[l][piece].second) {
+                        piece++;
+                        piece_off = 0;
+                    }
+                }
+                seq_ += n;
+                left -= n;
+                outs.push_back({out, l});
+            } while (left > 0);
+        }
+        tables_->template launch<tuple_t>(s);
+        for (auto& ol : outs) {
+            ol.first->ready.record(s);
+            emit_to(ol.first, ol.second);
+        }
+        xstats_->lane_batches += outs.size();
+    }
+
+    // send buffers whose round the peers are done with go back to their pool
+    bool release_sent() {
+        bool any = false;
+        while (!sent_.empty() && tr_->sends_done(sent_.front().first)) {
+            if (sent_.front().second != nullptr) sent_.front().second->release_host();
+            sent_.pop_front();
+            any = true;
+        }
+        return any;
+    }
+
+    // one rank: the exchange is the device KeyBy; the ready packed slabs of all local lanes are merged into lane batches
+    bool pump_single() {
+        bool progress = false;
+        hipStream_t s = stream_->get();
+        while (!pending_.empty()) {
+            if (pending_.front()->passthrough != nullptr) {  // one lane: nothing to partition
+                std::unique_ptr<ExchangeBundle> b(pending_.front());
+                pending_.pop_front();
+                if (b->hdr.reserved[0] != 0) note_local_punctuation(b->hdr.reserved[0]);
+                b->passthrough->host_hdr.reserved[0] = take_global_step(local_step_done_);  // the host view of the header is what travels downstream
+                emit_to(b->passthrough, 0);
+                xstats_->bundles++;
+                xstats_->lane_batches++;
+            } else {
+                std::vector<std::unique_ptr<ExchangeBundle>> take;
+                if (take_ready(take, false) == 0) break;
+                const size_t L = xcfg_.out_lanes;
+                src_list_t lane_src[dist::MAX_LANES];
+                uint64_t wm = 0, created = 0;
+                size_t total = 0;
+                for (auto& b : take) {
+                    my_cap_ = std::max(my_cap_, b->capacity);
+                    if (b->hdr.reserved[0] != 0) note_local_punctuation(b->hdr.reserved[0]);
+                    wm = std::max(wm, b->hdr.watermark);
+                    if (b->hdr.created_ns != 0) created = created == 0 ? b->hdr.created_ns : std::min(created, b->hdr.created_ns);
+                    for (size_t l = 0; l < L; l++) {
+                        const size_t lo = b->offsets[l], c = b->offsets[l + 1] - lo;
+                        if (c > 0) lane_src[l].push_back({b->packed->template data<tuple_t>() + lo, c});
+                        total += c;
+                    }
+                }
+                const uint64_t step_out = take_global_step(local_step_done_);
+                if (total > 0 || step_out != 0) emit_lanes(lane_src, wm, created, step_out, s);
+                for (auto& b : take) b->packed->release(s);
+                xstats_->bundles += take.size();
+                xstats_->tuples_received += total;
+            }
+            xstats_->rounds++;
+            progress = true;
+        }
+        if (done_ && pending_.empty()) finished_ = true;
+        return progress;
+    }
+
+    gpu::Batch* acquire(std::unique_ptr<gpu::BatchPool>& pool, size_t& pool_cap, size_t need, size_t slabs) {
+        if (!pool || pool_cap < need) {
+            // batches of the old pool may still be in flight: keep it alive until the end
+            if (pool) retired_pools_.push_back(std::move(pool));
+            pool_cap = need;
+            pool.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(tuple_t), pool_cap, slabs));
+        }
+        return pool->acquire(stream_->get());
+    }
+
+    // a step is locally complete when every local lane has punctuated it
+    void note_local_punctuation(uint64_t step) {
+        if (++punct_seen_[step] >= xcfg_.local_lanes) {
+            local_step_done_ = std::max(local_step_done_, step);
+            punct_seen_.erase(step);
+        }
+    }
+    // returns the step id to announce downstream (0: none) given the minimum step all ranks completed
+    uint64_t take_global_step(uint64_t min_step) {
+        if (min_step != UINT64_MAX && min_step > announced_step_) {
+            announced_step_ = min_step;
+            return min_step;
+        }
+        return 0;
+    }
+
+    std::shared_ptr<dist::Transport> tr_;
+    ExchangeConfig xcfg_;
+    GPUConfig cfg_;
+    std::shared_ptr<ExchangeStats> xstats_;
+    std::shared_ptr<size_t> n_producers_;
+    std::unique_ptr<gpu::Stream> stream_;
+    std::unique_ptr<gpu::SegTables> tables_;
+    std::unique_ptr<gpu::BatchPool> send_pool_, stage_pool_, lane_pool_;
+    std::vector<std::unique_ptr<gpu::BatchPool>> retired_pools_;
+    size_t group_ = 1;
+    size_t my_cap_ = 0, cap_ = 0, send_cap_ = 0, stage_cap_ = 0, lane_cap_ = 0;
+    std::deque<ExchangeBundle*> pending_;                  // bundles not yet part of a round
+    std::deque<Staged> staged_;                            // rounds prepared, not yet published
+    std::deque<gpu::Batch*> open_;                         // send buffer (or nullptr) of every published, not yet collected round
+    std::deque<std::pair<uint64_t, gpu::Batch*>> sent_;    // rounds whose send buffers the peers may still be reading
+    uint64_t pub_ = 0, col_ = 0;
+    uint64_t seq_ = 0, last_round_us_ = 0, start_us_ = 0;
+    uint64_t local_step_done_ = 0, announced_step_ = 0;
+    uint64_t rank_wm_[dist::MAX_WORLD] = {};
+    bool rank_done_[dist::MAX_WORLD] = {};
+    std::map<uint64_t, size_t> punct_seen_;
+    bool done_ = false, finished_ = false;
+};
+
+// The two stages in front of a consumer with `lanes` replicas: (1) one packing node per producer, fused onto it;
+// (2) the endpoint, whose `lanes` output ports feed the consumer's replicas one to one.  `tr` == nullptr: the KeyBy inside a GPU.
+template <typename tuple_t>
+inline std::vector<StageSpec> exchange_stages(rt::Graph& g, std::shared_ptr<dist::Transport> tr, const std::string& name, GPUConfig cfg, ExchangeConfig xcfg,
+                                              edge_kind_t in_kind, std::shared_ptr<StatsHub> hub, std::shared_ptr<ExchangeStats> xstats = nullptr,
+                                              meta::closing_func_t closing = nullptr) {
+    cfg.gpu_id = cfg.device_for(0);
+    cfg.gpu_ids.clear();
+    const int world = tr ? tr->world() : 1;
+    auto n_producers = std::make_shared<size_t>(0);
+    StageSpec a;
+    a.name = name + "_partition";
+    a.routing = FORWARD;
+    const size_t lanes = xcfg.out_lanes;
+    a.per_producer = [=](size_t i, size_t n) -> rt::Node* {
+        *n_producers = n;
+        return new ExchangePart_Node<tuple_t>(world, lanes, cfg, in_kind, name + "_partition", n, i, nullptr, hub);
+    };
+    StageSpec b;
+    b.name = name;
+    b.routing = FORWARD;
+    b.internal = true;
+    rt::Node* ep = g.adopt(new ExchangeEndpoint_Node<tuple_t>(tr, xcfg, cfg, name, closing, hub, xstats, n_producers));
+    b.replicas.push_back(ep);
+    // one output port per lane: the operator behind sees `out_lanes` producers
+    for (size_t l = 0; l < lanes; l++) b.outputs.push_back(ep);
+    b.make_emitter = [](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(1), 1); };
+    return {a, b};
+}
+
+// KeyBy inside one GPU for a keyed operator with `lanes` replicas (see the top of this file)
+template <typename tuple_t>
+inline std::vector<StageSpec> device_keyby_stages(rt::Graph& g, const std::string& op_name, const GPUConfig& cfg, size_t lanes, edge_kind_t in_kind,
+                                                  std::shared_ptr<StatsHub> hub) {
+    ExchangeConfig xcfg;
+    xcfg.out_lanes = lanes;
+    return exchange_stages<tuple_t>(g, nullptr, op_name + "_keyby", cfg, xcfg, in_kind, std::move(hub));
+}
+
+}  // namespace wf

@@ -9,13 +9,17 @@
 //                                wave scan by pane.  Panes that begin and end inside the chunk are final: they are written as
 //                                LEAVES of the run (a flat array of pane aggregates, the run's FlatFAT leaf level); the first
 //                                and the last segment of a chunk may continue in its neighbours: they are left as PARTIALS
-//   3. ffat_huge_fix_kernel      one wave per run: stitches the partials in order (a few per chunk), fills the panes no
-//                                tuple fell into (time-based windows), appends the panes to the key's tree in HBM, advances
-//                                the key's state and reserves room in the output batch for the windows the run fires
-//   4. ffat_huge_windows_kernel  one thread per fired window over the leaves (old panes of the key in front, new ones behind)
+//   3. ffat_huge_stitch_kernel   one wave per 64 partials (two per chunk, in run order): the same segmented scan joins the
+//                                pieces of a pane that straddles chunks; panes that end inside the 64 are final (leaves),
+//                                the first and the last are again partials, of the next level (64 times fewer)
+//   4. ffat_huge_fix_kernel      one wave per run: stitches the second-level partials with what was open before the run,
+//                                fills the panes no tuple fell into (time-based windows), appends the panes to the key's
+//                                tree in HBM, advances the key's state and reserves room in the output batch for the
+//                                windows the run fires
+//   5. ffat_huge_windows_kernel  one thread per fired window over the leaves (old panes of the key in front, new ones behind)
 // Used for count-based windows and for time-based windows without triggering delay whose run is in timestamp order and not
 // sparse in time; everything else (and windows of more than FFAT_HUGE_MAX_WIN panes) goes to the wave-per-run kernel, which
-// implements the full rules.  The engine switches these four launches on when a batch shows a huge run and off again after
+// implements the full rules.  The engine switches these five launches on when a batch shows a huge run and off again after
 // a while without one (key_ffat_gpu.hpp), so streams without hot keys do not pay for them.
 //
 // Reference: the reference engine (wf/win_seqffat_gpu.hpp:369-396 + wf/flatfat_gpu.hpp:251-434) handles ONE key per replica
@@ -35,15 +39,16 @@ template <typename R>
 struct FFATPartial {
     R val;
     uint32_t pane;   // relative to the first pane the run can complete
-    uint32_t valid;
+    uint32_t valid;  // 1: a value; 2: a place holder without value (the unit has a single segment: `pane` is that segment's pane)
 };
 
 struct FFATHugeCtl {
-    uint32_t n_runs, total_chunks, pad0, pad1;
+    uint32_t n_runs, total_chunks, total_units, pad1;
 };
 
 struct FFATHugeRun {
     uint32_t head, len, slot, n_chunks;
+    uint32_t n_units, unit_base;  // second level: a unit stitches 64 first-level partials (32 chunks)
     uint32_t chunk_base;  // first chunk of the run in the batch-wide chunk numbering
     uint32_t leaf_base;   // first leaf of the run in the scratch: win_panes - 1 old panes, then the panes of the run
     uint32_t max_panes, pc0;
@@ -93,22 +98,27 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t chunks = 0, leaves = 0;
+        uint32_t chunks = 0, leaves = 0, units = 0;
         for (uint32_t r = 0; r < nr; r++) {
             FFATHugeRun& hr = runs[r];
             const uint32_t need = hr.fallback ? 0 : (win_panes - 1) + hr.max_panes;
             if (leaves + need > leaves_cap) hr.fallback = 1;  // cannot happen with the sizes the engine allocates; stay safe
             hr.chunk_base = chunks;
+            hr.unit_base = units;
             hr.leaf_base = leaves;
             if (!hr.fallback) {
+                hr.n_units = (2 * hr.n_chunks + WAVE - 1) / WAVE;
                 chunks += hr.n_chunks;
+                units += hr.n_units;
                 leaves += need;
             } else {
                 hr.n_chunks = 0;
+                hr.n_units = 0;
             }
         }
         ctl->n_runs = nr;
         ctl->total_chunks = chunks;
+        ctl->total_units = units;
     }
 }
 
@@ -187,7 +197,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 leaves[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)pane] = v;
             }
         }
-        if (lane == 0 && n_segs < 2) my_parts[1].valid = 0;
+        if (lane == 0 && n_segs < 2) {
+            my_parts[1].pane = (uint32_t)pane;  // (lane 0 sits in the only segment)
+            my_parts[1].valid = 2;
+        }
         if (is_tb) {
             // quanta between two segments of this chunk that received nothing: empty panes
             const uint64_t gap = boundary && lane > 0 ? pane - prev - 1 : 0;
@@ -202,14 +215,112 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// Segmented, order-preserving scan over up to 64 consecutive partials (lane l holds one; `ok`: the lane holds an entry,
+// `has`: the entry carries a value).  Entries of one pane are contiguous.  Afterwards the tail lane of every segment holds
+// the segment's aggregate.
+template <typename R>
+struct FFATStitched {
+    R val;
+    bool has, boundary, tail;
+    int seg, n_segs;
+    uint32_t prev_pane;  // pane of the entry in the lane below (undefined for lane 0)
+    uint32_t cnt;        // lanes that hold an entry
+};
+template <typename R, typename C>
+__device__ __forceinline__ FFATStitched<R> ffat_stitch_wave(bool ok, uint32_t pane, bool has, const R& v, const C& comb) {
+    const int lane = lane_id();
+    FFATStitched<R> o;
+    o.val = v;
+    o.has = has;
+    o.prev_pane = (uint32_t)__shfl_up((int)pane, 1, WAVE);
+    o.boundary = ok && (lane == 0 || o.prev_pane != pane);
+    const unsigned long long okmask = __ballot(ok);  // a prefix of the lanes
+    o.cnt = (uint32_t)__popcll(okmask);
+    const unsigned long long bmask = __ballot(o.boundary);
+    o.seg = __popcll(bmask & (lanemask_lt() | (1ull << lane))) - 1;
+    o.n_segs = __popcll(bmask);
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int oseg = __shfl_up(o.seg, d, WAVE);
+        const bool take = ok && lane >= d && oseg == o.seg;
+        if (__ballot(take) == 0) break;
+        const R other = wave_shfl_up(o.val, d);
+        const bool other_has = __shfl_up((int)o.has, d, WAVE) != 0;
+        if (take && other_has) {
+            if (o.has) {
+                R tmp;
+                fat_combine(comb, other, o.val, tmp);
+                o.val = tmp;
+            } else {
+                o.val = other;
+                o.has = true;
+            }
+        }
+    }
+    o.tail = ok && ((lane + 1 == (int)o.cnt) || ((bmask >> (lane + 1)) & 1ull));
+    return o;
+}
+
+template <typename R, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_stitch_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const FFATPartial<R>* parts, FFATPartial<R>* parts2,
+                            R* leaves, const unsigned long long* table, C comb) {
+    const uint32_t total = ctl->total_units, nr = ctl->n_runs;
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    const int lane = lane_id();
+    for (uint32_t u = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); u < total; u += waves_total) {
+        uint32_t lo = 0, hi = nr;
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (runs[mid].unit_base <= u)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        while (runs[lo].n_units == 0 && lo > 0) lo--;
+        const FFATHugeRun& hr = runs[lo];
+        if (hr.fallback) continue;
+        const uint32_t e = (u - hr.unit_base) * WAVE + (uint32_t)lane, n_entries = 2 * hr.n_chunks;
+        const bool ok = e < n_entries;
+        FFATPartial<R> pe{};
+        if (ok) pe = parts[2 * (size_t)hr.chunk_base + e];
+        const FFATStitched<R> st = ffat_stitch_wave(ok, pe.pane, ok && pe.valid == 1, pe.val, comb);
+        using key_t = decltype(cf_key(pe.val));
+        const key_t key = (key_t)table[hr.slot];
+        R* lv = leaves + (size_t)hr.leaf_base + (g.win_panes - 1);
+        FFATPartial<R>* mine = parts2 + 2 * (size_t)u;
+        if (st.tail) {
+            if (st.seg == 0 || st.seg == st.n_segs - 1) {
+                FFATPartial<R>& dst = mine[st.seg == 0 ? 0 : 1];
+                dst.val = st.val;
+                dst.pane = pe.pane;
+                dst.valid = 1;
+            } else {
+                R x = st.val;
+                if (g.is_tb) x.setControlFields(key, hr.Lq + pe.pane, (hr.Lq + pe.pane + 1) * g.pane_len - 1);
+                lv[pe.pane] = x;
+            }
+        }
+        if (lane == 0 && st.n_segs < 2) {
+            mine[1].pane = pe.pane;
+            mine[1].valid = 2;
+        }
+        // time-based: an even entry is the first partial of its chunk; the panes between it and the entry before it belong to
+        // no chunk and received nothing (the panes between the two partials of one chunk are the chunk's own)
+        if (g.is_tb && st.boundary && lane > 0 && (e & 1u) == 0) {
+            for (uint32_t p = st.prev_pane + 1; p < pe.pane; p++) {
+                R x{};
+                x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+                lv[p] = x;
+            }
+        }
+    }
+}
+
 template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
-                         const FFATHugeCtl* ctl, const FFATPartial<R>* parts, R* leaves, uint32_t* out_count, uint32_t* long_heads, uint32_t* n_long,
+                         const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint32_t* out_count, uint32_t* long_heads, uint32_t* n_long,
                          const unsigned long long* table, FFATCounters* ctr, C comb) {
-    // (raw bytes: result types with default member initialisers cannot be declared __shared__)
-    __shared__ __align__(16) char s_raw[(BLOCK_THREADS / WAVE) * WAVE * sizeof(FFATPartial<R>)];
-    FFATPartial<R>* s_mine = reinterpret_cast<FFATPartial<R>*>(s_raw) + (size_t)wave_id() * WAVE;
     const uint32_t nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -230,7 +341,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             const uint64_t back = (uint64_t)(W - 1 - j);  // pane P0 - back
             if (hr.P0 >= back) lv[-(int64_t)back] = gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))];
         }
-        // what was open before the run is the head of pane 0
+        // what was open before the run is the head of pane 0 (the carry is kept identical in every lane)
         bool c_has = false;
         uint32_t c_pane = 0;
         R c_val{};
@@ -251,7 +362,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         wave_sync_lds();
         if (g.is_tb && lane == 0)
             for (uint32_t a = 0; a < g.acc_cap; a++) used[a] = 0;
-        auto put_leaf = [&](uint32_t p, const R& v) {  // lane 0
+        auto put_leaf = [&](uint32_t p, const R& v) {
             R x = v;
             if (g.is_tb) x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
             lv[p] = x;
@@ -264,50 +375,37 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 lv[p] = e;
             }
         };
-        const uint32_t n_parts = 2 * hr.n_chunks;
-        for (uint32_t e0 = 0; e0 < n_parts; e0 += WAVE) {
+        const uint32_t n_entries = 2 * hr.n_units;
+        for (uint32_t e0 = 0; e0 < n_entries; e0 += WAVE) {
             const uint32_t e = e0 + (uint32_t)lane;
-            if (e < n_parts) s_mine[lane] = parts[2 * (size_t)hr.chunk_base + e];
-            wave_sync_lds();
-            const uint32_t ne = n_parts - e0 < (uint32_t)WAVE ? n_parts - e0 : (uint32_t)WAVE;
-            // lane 0 stitches; the gaps it finds are filled by the whole wave afterwards (their bounds go through LDS-free
-            // registers of lane 0 and a broadcast)
-            for (uint32_t k = 0; k < ne; k++) {
-                uint32_t gap_from = 0, gap_to = 0;
-                if (lane == 0) {
-                    const FFATPartial<R>& pe = s_mine[k];
-                    if (pe.valid) {
-                        if (c_has && c_pane == pe.pane) {
-                            R tmp;
-                            fat_combine(comb, c_val, pe.val, tmp);
-                            c_val = tmp;
-                        } else {
-                            if (c_has) put_leaf(c_pane, c_val);
-                            // (the interior panes of a chunk lie between its two partials and were written by the chunk)
-                            if (g.is_tb) {
-                                const bool same_chunk = ((e0 + k) & 1u) != 0;  // second partial of its chunk
-                                const uint32_t lo_p = c_has ? c_pane + 1 : 0;
-                                if (!same_chunk && pe.pane > lo_p) {
-                                    gap_from = lo_p;
-                                    gap_to = pe.pane;
-                                }
-                            }
-                            c_has = true;
-                            c_pane = pe.pane;
-                            c_val = pe.val;
-                        }
-                    }
+            const bool ok = e < n_entries;
+            FFATPartial<R> pe{};
+            if (ok) pe = parts2[2 * (size_t)hr.unit_base + e];
+            FFATStitched<R> sw = ffat_stitch_wave(ok, pe.pane, ok && pe.valid == 1, pe.val, comb);
+            // the carry joins the first segment, or is final
+            const uint32_t pane0 = (uint32_t)__shfl((int)pe.pane, 0, WAVE);
+            if (c_has && c_pane == pane0) {
+                if (sw.tail && sw.seg == 0) {
+                    R tmp;
+                    fat_combine(comb, c_val, sw.val, tmp);
+                    sw.val = tmp;
                 }
-                if (g.is_tb) {
-                    gap_from = (uint32_t)__shfl((int)gap_from, 0, WAVE);
-                    gap_to = (uint32_t)__shfl((int)gap_to, 0, WAVE);
-                    if (gap_to > gap_from) fill_gap(gap_from, gap_to);
-                }
+            } else {
+                if (c_has && lane == 0) put_leaf(c_pane, c_val);
+                if (g.is_tb) fill_gap(c_has ? c_pane + 1 : 0, pane0);  // (lane 0 always holds the first partial of a unit)
             }
-            wave_sync_lds();
+            if (sw.tail && sw.seg < sw.n_segs - 1) put_leaf(pe.pane, sw.val);
+            if (g.is_tb && sw.boundary && lane > 0 && (e & 1u) == 0)
+                for (uint32_t p = sw.prev_pane + 1; p < pe.pane; p++) put_leaf(p, R{});
+            // the last segment is the new carry
+            const int last = (int)sw.cnt - 1;
+            c_val = wave_bcast(sw.val, last);
+            c_pane = (uint32_t)__shfl((int)pe.pane, last, WAVE);
+            c_has = true;
         }
+        wave_sync_lds();
         // the last pane of the run: complete (count-based, when the run ends on a pane boundary) or left open
-        uint32_t m;
+        uint32_t m = 0;
         if (lane == 0) {
             if (!g.is_tb) {
                 const uint64_t total = (uint64_t)hr.pc0 + hr.len;

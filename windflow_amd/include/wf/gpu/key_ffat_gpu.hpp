@@ -29,6 +29,7 @@
 
 #include "batch_ops.hpp"
 #include "flatfat_gpu.hpp"
+#include "../dist/exchange_nodes.hpp"
 #include "keyby_gpu.hpp"
 #include "primitives.hpp"
 
@@ -777,6 +778,7 @@ public:
             huge_runs_.resize(huge_max_runs_);
             huge_ctl_.resize(1);
             huge_parts_.resize(2 * (batch_cap_ / WAVE + huge_max_runs_));
+            huge_parts2_.resize(2 * (2 * (batch_cap_ / WAVE + huge_max_runs_) / WAVE + huge_max_runs_));
             huge_leaves_.resize(huge_leaves_cap_);
             WF_HIP_CHECK(hipHostMalloc((void**)&huge_seen_, 64, hipHostMallocDefault));
             *huge_seen_ = 0;
@@ -872,9 +874,12 @@ private:
                 hipLaunchKernelGGL((ffat_huge_chunks_kernel<T, R, L, C>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, in->template data<T>(), sorted.vals,
                                    g_.pane_len, g_.is_tb, g_.win_panes, huge_runs_.data(), huge_ctl_.data(), huge_parts_.data(), huge_leaves_.data(),
                                    lift_, comb_);
+                const unsigned sgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (upper / WAVE / 32 + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
+                hipLaunchKernelGGL((ffat_huge_stitch_kernel<R, C>), dim3(sgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
+                                   huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), table_.data(), comb_);
                 const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
-                                   acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts_.data(), huge_leaves_.data(),
+                                   acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
                                    out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
                 hipLaunchKernelGGL((ffat_huge_windows_kernel<R, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
                                    huge_leaves_.data(), out->template data<R>(), counters_.data(), table_.data(), comb_);
@@ -945,7 +950,7 @@ private:
     DeviceBuffer<uint32_t> huge_heads_;
     DeviceBuffer<FFATHugeRun> huge_runs_;
     DeviceBuffer<FFATHugeCtl> huge_ctl_;
-    DeviceBuffer<FFATPartial<R>> huge_parts_;
+    DeviceBuffer<FFATPartial<R>> huge_parts_, huge_parts2_;
     DeviceBuffer<R> huge_leaves_;
     // hipGraph cache
     struct GraphKey {
@@ -1090,16 +1095,18 @@ public:
         const size_t N = par_;
         const edge_kind_t kind = *kind_;
         if (kind != EDGE_TUPLE && !wcfg_.lanes_are_key_disjoint && N > 1) {
-            // device KeyBy: the emitter ships host batches itself and hands device sub-batches over
+            // device KeyBy (dist/exchange_nodes.hpp): every producer packs its batches by replica, one endpoint thread merges the
+            // packed slabs of all producers into one device batch per replica
             *kind_ = EDGE_DEVICE_BATCH;
+            GPUConfig kcfg;
+            kcfg.gpu_id = gpu_id_;
+            kcfg.pool_slabs = slabs_;
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, kcfg, N, kind, hub_);
             s.replicas = factory_(g);
-            s.routing = COMPLEX;
-            const int dev = gpu_id_;
-            const size_t slabs = slabs_;
-            s.make_emitter = [N, kind, dev, slabs](rt::Graph& gr, size_t) {
-                return single_emitter(gr, new KeyBy_EmitterGPU<tuple_t>(N, kind, dev, slabs), N);
-            };
-            return {s};
+            s.routing = FORWARD;  // lane i of the endpoint -> replica i
+            s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
+            stages.push_back(s);
+            return stages;
         }
         s.replicas = factory_(g);
         if (*kind_ == EDGE_TUPLE) {

@@ -18,6 +18,7 @@
 // indexed by slot (zero-initialised when a key first appears).
 #pragma once
 #include "batch_ops.hpp"
+#include "../dist/exchange_nodes.hpp"
 #include "keyby_gpu.hpp"
 #include "kernels_basic.hpp"
 #include "primitives.hpp"
@@ -396,13 +397,13 @@ public:
             s.replicas = factory_(g, kind);
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
         } else {
-            s.routing = KEYBY;
-            s.replicas = factory_(g, EDGE_DEVICE_BATCH);  // the emitter ships host batches to the device itself
-            const int dev = cfg_.gpu_id;
-            const size_t slabs = cfg_.pool_slabs;
-            s.make_emitter = [N, kind, dev, slabs](rt::Graph& gr, size_t) {
-                return single_emitter(gr, new KeyBy_EmitterGPU<tuple_t>(N, kind, dev, slabs), N);
-            };
+            // device KeyBy (dist/exchange_nodes.hpp): producers pack their batches by replica, one endpoint merges them per replica
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_);
+            s.routing = FORWARD;
+            s.replicas = factory_(g, EDGE_DEVICE_BATCH);
+            s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
+            stages.push_back(s);
+            return stages;
         }
         return {s};
     }

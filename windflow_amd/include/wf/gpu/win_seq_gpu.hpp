@@ -27,6 +27,7 @@
 #include "../win_mapreduce.hpp"
 #include "../win_seq.hpp"
 #include "batch_ops.hpp"
+#include "../dist/exchange_nodes.hpp"
 #include "keyby_gpu.hpp"
 #include "win_batch_gpu.hpp"
 
@@ -59,7 +60,7 @@ public:
     edge_kind_t kind = EDGE_TUPLE;
     size_t slabs() const { return cfg_.pool_slabs; }
 
-    std::vector<StageSpec> build(rt::Graph& g) {
+    std::vector<StageSpec> build(rt::Graph& g, std::shared_ptr<StatsHub> hub_ = nullptr) {
         StageSpec s;
         s.name = name_;
         const size_t N = par_;
@@ -82,11 +83,12 @@ public:
             s.make_emitter = [rf, N](rt::Graph& gr, size_t) { return single_emitter(gr, new KF_Emitter<tuple_t>(rf, N), N); };
             s.make_ordering = window_ordering<tuple_t>(type_, name_);
         } else if (keyby) {
-            s.routing = COMPLEX;
-            const edge_kind_t in = kind;
-            const int dev = cfg_.gpu_id;
-            const size_t slabs = cfg_.pool_slabs;
-            s.make_emitter = [N, in, dev, slabs](rt::Graph& gr, size_t) { return single_emitter(gr, new KeyBy_EmitterGPU<tuple_t>(N, in, dev, slabs), N); };
+            // device KeyBy (dist/exchange_nodes.hpp): producers pack their batches by replica, one endpoint merges them per replica
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_);
+            s.routing = FORWARD;
+            s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
+            stages.push_back(s);
+            return stages;
         } else {
             s.routing = FORWARD;  // lane i -> replica i
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
@@ -144,7 +146,7 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
         return flat_ ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
     }
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return flat_ ? flat_->build(g) : base_t::build_stages(g, m); }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return flat_ ? flat_->build(g, this->hub_) : base_t::build_stages(g, m); }
     // per-replica device counters, valid after the end of the run
     std::vector<gpu::WinCounters> getDeviceCounters() const { return counters_ ? *counters_ : std::vector<gpu::WinCounters>(); }
 
@@ -192,7 +194,7 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
         return batch_path() ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
     }
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return batch_path() ? flat_->build(g) : base_t::build_stages(g, m); }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return batch_path() ? flat_->build(g, this->hub_) : base_t::build_stages(g, m); }
     std::vector<gpu::WinCounters> getDeviceCounters() const { return counters_ ? *counters_ : std::vector<gpu::WinCounters>(); }
 
 private:

@@ -395,6 +395,19 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
     std::vector<Endpoint> prev = tails_;
     for (size_t si = 0; si < stages.size(); si++) {
         StageSpec& s = stages[si];
+        if (s.per_producer) {
+            // one node per upstream endpoint, in the producer's thread
+            for (size_t i = 0; i < prev.size(); i++) {
+                rt::Node* node = g.adopt(s.per_producer(i, prev.size()));
+                g.connect_fused(prev[i].node, prev[i].port, node);
+                s.replicas.push_back(node);
+            }
+            force_shuffle_ = false;
+            fresh_from_split_ = false;
+            prev.clear();
+            for (rt::Node* r : s.replicas) prev.push_back({r, r->add_out_port()});
+            continue;
+        }
         const size_t n = s.replicas.size();
         const bool last_stage = (si + 1 == stages.size());
         const bool can_chain = try_chain && stages.size() == 1 && s.routing == FORWARD && !fresh_from_split_ && !force_shuffle_ &&
