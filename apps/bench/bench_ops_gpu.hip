@@ -10,6 +10,8 @@
 //   -o map_stateless     in-place map doing a lookup in a device hash table
 //   -o filter_stateless  predicate + on-device stable compaction
 //   -o map_stateful      keyed map: per-key window of the last 1000 values, incremental average (8 KB of state per key)
+//   -o map_sum           keyed map with the cheapest state there is (a running sum per key)
+//   -o map_scan          the same running sum in the associative form keyed_scan(lift, combine, apply): a wave folds 64 tuples of a key per step
 //   -o filter_stateful   keyed filter on the same state: keeps tuples above the running average
 //   -o keyby             device KeyBy only (scattering study): S lanes re-partitioned into N
 //
@@ -86,6 +88,24 @@ struct WindowState {
 struct RunningAverageMap {
     __host__ __device__ void operator()(tuple_t& t, char* state, size_t) const { t.aux = reinterpret_cast<WindowState*>(state)->push(t.value); }
 };
+// the cheapest stateful function there is (a running sum): what is left is the cost of the keyed machinery itself
+struct RunningSumMap {
+    __host__ __device__ void operator()(tuple_t& t, char* state, size_t) const {
+        double& s = *reinterpret_cast<double*>(state);
+        s += t.value;
+        t.aux = s;
+    }
+};
+// the same running sum in the associative form: keyed_scan(lift, combine, apply)
+struct SumLift {
+    __host__ __device__ void operator()(const tuple_t& t, double& s) const { s = t.value; }
+};
+struct SumCombine {
+    __host__ __device__ void operator()(const double& a, const double& b, double& out) const { out = a + b; }
+};
+struct SumApply {
+    __host__ __device__ void operator()(tuple_t& t, const double& s) const { t.aux = s; }
+};
 struct AboveAverageFilter {
     __host__ __device__ void operator()(const tuple_t& t, bool& keep, char* state, size_t) const {
         keep = t.value >= reinterpret_cast<WindowState*>(state)->push(t.value);
@@ -159,7 +179,7 @@ int main(int argc, char** argv) {
             case 't': seconds = std::atof(optarg); break;
             case 'd': device_source = true; break;
             default:
-                std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|filter_stateful|keyby|win_agg [-s sources] [-n replicas] "
+                std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|map_sum|map_scan|filter_stateful|keyby|win_agg [-s sources] [-n replicas] "
                           << "[-k keys] [-b batch] [-t seconds] [-d (generate on the device)]" << std::endl;
                 return 0;
         }
@@ -224,6 +244,14 @@ int main(int argc, char** argv) {
         auto b = MapGPU_Builder(RunningAverageMap()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))
                      .withMaxKeys(max_keys);
         if (disjoint && op != "keyby") b.withKeyDisjointLanes();
+        oper = b.build_unique();
+    } else if (op == "map_sum") {
+        auto b = MapGPU_Builder(RunningSumMap()).withName(op).withParallelism(replicas).withScratchpad(sizeof(double)).withMaxKeys(max_keys);
+        if (disjoint) b.withKeyDisjointLanes();
+        oper = b.build_unique();
+    } else if (op == "map_scan") {
+        auto b = ScanMapGPU_Builder(keyed_scan(SumLift(), SumCombine(), SumApply())).withName(op).withParallelism(replicas).withMaxKeys(max_keys);
+        if (disjoint) b.withKeyDisjointLanes();
         oper = b.build_unique();
     } else if (op == "filter_stateful") {
         auto b = FilterGPU_Builder(AboveAverageFilter()).withName(op).withParallelism(replicas).withScratchpad(sizeof(WindowState))

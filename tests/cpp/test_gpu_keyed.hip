@@ -22,6 +22,26 @@ struct RunningSum {
         t.value = *acc;
     }
 };
+// the associative form of a keyed map: the history of a key is (sum, newest value) - the second field makes the combine
+// non-commutative, so a wrong operand order shows
+struct Hist {
+    int64_t sum, newest;
+};
+struct HistLift {
+    __host__ __device__ void operator()(const tuple_t& t, Hist& h) const {
+        h.sum = t.value;
+        h.newest = t.value;
+    }
+};
+struct HistCombine {
+    __host__ __device__ void operator()(const Hist& older, const Hist& newer, Hist& out) const {
+        out.sum = older.sum + newer.sum;
+        out.newest = newer.newest;
+    }
+};
+struct HistApply {
+    __host__ __device__ void operator()(tuple_t& t, const Hist& h) const { t.value = h.sum + 1000 * (h.newest - t.value); }  // newest == own value
+};
 // out-of-place flavour
 struct RunningSumOut {
     __host__ __device__ void operator()(const tuple_t& t, output_t& r, char* state, size_t) const {
@@ -141,6 +161,29 @@ int main(int argc, char** argv) {
             g.run();
             const bool ok = (sum == exp_a && cnt == (long)n);
             cout << "A par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        // ---- H: the same running sum as a parallel scan (keyed_scan), fed with tuples and with batches ----------------------
+        for (int batched = 0; batched < 2; batched++) {
+            PipeGraph g("keyed_h", Mode::DEFAULT);
+            Source tsrc = Source_Builder(Gen(n, keys)).withParallelism(1).build();
+            auto bsrc = BatchSource_Builder(Gen(n, keys)).withParallelism(1).withBatch(batch).build_unique();
+            MultiPipe& mp = batched ? g.add_source(*bsrc) : g.add_source(tsrc);
+            auto map = ScanMapGPU_Builder(keyed_scan(HistLift(), HistCombine(), HistApply())).withName("scanmap").withParallelism(p1).withBatch(batch)
+                           .withMaxKeys(keys).build_unique();
+            mp.add(*map);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                            if (o) {
+                                sum += o->value;
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_a && cnt == (long)n);
+            cout << "H keyed_scan " << (batched ? "batches" : "tuples") << " par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt
+                 << " (expected " << exp_a << ")" << (ok ? "  OK" : "  FAILED") << endl;
             failures += !ok;
         }
         // ---- B ----------------------------------------------------------------

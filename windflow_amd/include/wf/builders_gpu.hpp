@@ -123,6 +123,45 @@ private:
     routing_func_t routing_ = default_routing;
 };
 
+// keyed_scan(lift, combine, apply): the associative form of a keyed in-place Map_GPU (gpu/keyed_gpu.hpp): hand the result
+// to ScanMapGPU_Builder.
+template <typename L, typename C, typename A>
+inline gpu::KeyedScan<L, C, A> keyed_scan(L lift, C combine, A apply) {
+    return gpu::KeyedScan<L, C, A>{lift, combine, apply};
+}
+template <typename F>
+class ScanMapGPU_Builder : public GPU_Builder_Base<ScanMapGPU_Builder<F>> {
+    static_assert(gpu::is_keyed_scan<F>::value, "ScanMapGPU_Builder takes keyed_scan(lift, combine, apply)");
+
+public:
+    using tuple_t = typename F::tuple_t;
+    using map_t = Keyed_GPU_Operator<3, tuple_t, tuple_t>;
+    explicit ScanMapGPU_Builder(F func) : GPU_Builder_Base<ScanMapGPU_Builder<F>>("scan_map_gpu"), func_(std::move(func)) {}
+    ScanMapGPU_Builder& withMaxKeys(size_t n) {
+        kcfg_.max_keys = n;
+        return *this;
+    }
+    ScanMapGPU_Builder& withRoutingFunction(routing_func_t r) {
+        routing_ = std::move(r);
+        return *this;
+    }
+    ScanMapGPU_Builder& withKeyDisjointLanes(bool b = true) {
+        kcfg_.lanes_are_key_disjoint = b;
+        return *this;
+    }
+    map_t* build_ptr() {
+        kcfg_.state_size = F::record_size;
+        return new map_t(func_, this->parallelism_, this->name_, kcfg_, this->cfg_, this->closing_, routing_);
+    }
+    map_t build() { return *std::unique_ptr<map_t>(build_ptr()); }
+    std::unique_ptr<map_t> build_unique() { return std::unique_ptr<map_t>(build_ptr()); }
+
+private:
+    F func_;
+    KeyedGPUConfig kcfg_;
+    routing_func_t routing_ = default_routing;
+};
+
 // Filter_GPU:  void(const T&, bool&) | bool(const T&)   stateless
 //              void(const T&, bool&, char*, size_t)      keyed, per-key scratchpad
 template <typename F>

@@ -5,6 +5,14 @@
 //     filter          : void(const tuple_t&, bool& keep, char* state, size_t size)
 // and the tuples of a key are processed in arrival order.
 //
+// A stream with few keys leaves such a function little parallelism: it is sequential per key by contract.  When the state
+// is a FOLD of the key's history (running sum / count / max / last value ...), keyed_scan(lift, combine, apply) says so:
+//     lift    : void(const tuple_t&, state_t&)                       the state of a history of one tuple
+//     combine : void(const state_t& older, const state_t& newer, state_t& out)   associative
+//     apply   : void(tuple_t&, const state_t& history)               history = every earlier tuple of the key and this one
+// and the tuples of a key are then processed as a parallel prefix scan: a wave folds 64 of them per step instead of one
+// (MODE 3 below).  No counterpart in the reference.
+//
 // Capability parity with the keyed variants of the fork's MapGPU_Node /
 // FilterGPU_Node (/root/reference/wf/map_gpu_node.hpp:89-125, :372-399, :492-496;
 // wf/filter_gpu_node.hpp:61-76) and with the stateful benchmarks
@@ -28,6 +36,24 @@ namespace gpu {
 
 // runs of at least this many tuples of one key go to the wave-per-run kernel
 constexpr uint32_t KEYED_LONG_RUN = 32;
+
+// the associative form of a keyed map (see the top of this file)
+template <typename L, typename C, typename A>
+struct KeyedScan {
+    using tuple_t = meta::arg_bare_t<L, 0>;
+    using state_t = meta::arg_bare_t<L, 1>;
+    static_assert(std::is_trivially_copyable_v<state_t> && sizeof(state_t) % 4 == 0, "keyed_scan: the state travels through wave shuffles (32-bit words)");
+    L lift;
+    C combine;
+    A apply;
+    // per-key record in the state slab: the state, then a word that says whether the key has a history yet
+    static constexpr size_t flag_offset = (sizeof(state_t) + 7) & ~size_t(7);
+    static constexpr size_t record_size = flag_offset + 8;
+};
+template <typename X>
+struct is_keyed_scan : std::false_type {};
+template <typename L, typename C, typename A>
+struct is_keyed_scan<KeyedScan<L, C, A>> : std::true_type {};
 
 // mode 0: in-place map, 1: out-of-place map, 2: filter flags
 template <int MODE, typename T, typename R, typename F>
@@ -54,9 +80,35 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             continue;
         }
         char* st = states + (size_t)slot * state_size;
+        if constexpr (MODE == 3) {
+            using S = typename F::state_t;
+            S acc{};
+            bool has = *reinterpret_cast<const uint32_t*>(st + F::flag_offset) != 0;
+            if (has) acc = *reinterpret_cast<const S*>(st);
+            for (uint32_t j = i; j < n && sslot[j] == slot; j++) {
+                const uint32_t p = sidx[j];
+                T t = data[p];
+                S x{};
+                f.lift(static_cast<const T&>(t), x);
+                if (has) {
+                    S tmp{};
+                    f.combine(static_cast<const S&>(acc), static_cast<const S&>(x), tmp);
+                    acc = tmp;
+                } else {
+                    acc = x;
+                    has = true;
+                }
+                f.apply(t, static_cast<const S&>(acc));
+                data[p] = t;
+            }
+            *reinterpret_cast<S*>(st) = acc;
+            *reinterpret_cast<uint32_t*>(st + F::flag_offset) = 1u;
+            continue;
+        }
         for (uint32_t j = i; j < n && sslot[j] == slot; j++) {
             const uint32_t p = sidx[j];
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 3) {
+            } else if constexpr (MODE == 0) {
                 T t = data[p];
                 f(t, st, state_size);
                 data[p] = t;
@@ -176,6 +228,98 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// the value of `v` held by lane `src` / by lane (lane - d): any trivially copyable struct made of 32-bit words
+template <typename X>
+__device__ __forceinline__ X keyed_shfl(const X& v, int src) {
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(X) / 4; k++) w[k] = __shfl(w[k], src, WAVE);
+    X o;
+    __builtin_memcpy(&o, w, sizeof(X));
+    return o;
+}
+template <typename X>
+__device__ __forceinline__ X keyed_shfl_up(const X& v, int d) {
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(X) / 4; k++) w[k] = __shfl_up(w[k], d, WAVE);
+    X o;
+    __builtin_memcpy(&o, w, sizeof(X));
+    return o;
+}
+
+// Long runs of the associative form: one wave64 per run, 64 tuples per step.  The lanes lift their tuples, an ordered
+// inclusive wave scan (6 shuffle + combine steps) gives every lane the fold of the chunk up to its tuple, the history of
+// the key before the chunk is combined in front, every lane applies its own tuple.
+template <typename T, typename F>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    keyed_scan_long_kernel(const BatchHeader* hdr, T* data, const uint32_t* sslot, const uint32_t* sidx, char* states, size_t state_size,
+                           const uint32_t* long_heads, const uint32_t* n_long, F f) {
+    using S = typename F::state_t;
+    const uint32_t n = hdr->count;
+    const uint32_t runs = *n_long;
+    const int lane = lane_id();
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < runs; r += waves_total) {
+        const uint32_t head = long_heads[r];
+        const uint32_t slot = sslot[head];
+        char* st = states + (size_t)slot * state_size;
+        S carry{};
+        bool has = *reinterpret_cast<const uint32_t*>(st + F::flag_offset) != 0;  // identical in every lane
+        if (has) carry = *reinterpret_cast<const S*>(st);
+        uint32_t j = head + (uint32_t)lane;
+        bool ok = (j < n) && (sslot[j] == slot);
+        uint32_t p = ok ? sidx[j] : 0;
+        T t{};
+        if (ok) t = data[p];
+        while (true) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(ok));  // the valid lanes are a prefix: the arrays are sorted
+            if (cnt == 0) break;  // the run ended exactly on the previous chunk
+            S val{};
+            if (ok) f.lift(static_cast<const T&>(t), val);
+            // the next chunk's loads go out now and complete while this one is scanned
+            T nt{};
+            bool nok = false;
+            uint32_t np = 0;
+            if (cnt == WAVE) {
+                j += WAVE;
+                nok = (j < n) && (sslot[j] == slot);
+                np = nok ? sidx[j] : 0;
+                if (nok) nt = data[np];
+            }
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const S other = keyed_shfl_up(val, d);
+                if (ok && lane >= d) {
+                    S tmp{};
+                    f.combine(other, static_cast<const S&>(val), tmp);
+                    val = tmp;
+                }
+            }
+            if (ok) {
+                if (has) {
+                    S tmp{};
+                    f.combine(static_cast<const S&>(carry), static_cast<const S&>(val), tmp);
+                    val = tmp;
+                }
+                f.apply(t, static_cast<const S&>(val));
+                data[p] = t;
+            }
+            carry = keyed_shfl(val, (int)cnt - 1);
+            has = true;
+            if (cnt < WAVE) break;
+            t = nt;
+            ok = nok;
+            p = np;
+        }
+        if (lane == 0) {
+            *reinterpret_cast<S*>(st) = carry;
+            *reinterpret_cast<uint32_t*>(st + F::flag_offset) = 1u;
+        }
+    }
+}
+
 struct KeyOfTupleK {
     template <typename T>
     __host__ __device__ uint64_t operator()(const T& t) const {
@@ -278,7 +422,7 @@ protected:
             since_check_ = 0;
             check_table();
         }
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 0 || MODE == 3) {
             launch_apply<tuple_t>(d, (tuple_t*)nullptr, (uint8_t*)nullptr, sorted, upper, grid, s);
             this->emit_device(d);
         } else if constexpr (MODE == 1) {
@@ -329,14 +473,22 @@ private:
         hipLaunchKernelGGL((gpu::keyed_apply_kernel<MODE, tuple_t, RR, F>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
                            d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
                            ctx_->table_full_counter(), ctx_->long_heads(), ctx_->n_long(), func_);
-        const auto lay = ctx_->long_layout(sizeof(tuple_t), MODE == 1 ? sizeof(RR) : (MODE == 2 ? 1 : 0));
-        const size_t lds = (gpu::BLOCK_THREADS / gpu::WAVE) * lay.first;
-        if (lds > 64 * 1024) gpu::failwith("keyed GPU operator: tuple type too large for the LDS staging buffers");
-        const unsigned lgrid =
-            (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / gpu::KEYED_LONG_RUN / (gpu::BLOCK_THREADS / gpu::WAVE) + 1));
-        hipLaunchKernelGGL((gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>), dim3(lgrid), dim3(gpu::BLOCK_THREADS), lds, s, d->header(),
-                           d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
-                           ctx_->long_heads(), ctx_->n_long(), lay.second, lay.first, func_);
+        if constexpr (MODE == 3) {
+            const unsigned sgrid =
+                (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / gpu::KEYED_LONG_RUN / (gpu::BLOCK_THREADS / gpu::WAVE) + 1));
+            hipLaunchKernelGGL((gpu::keyed_scan_long_kernel<tuple_t, F>), dim3(sgrid), dim3(gpu::BLOCK_THREADS), 0, s, d->header(),
+                               d->template data<tuple_t>(), sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(), ctx_->long_heads(),
+                               ctx_->n_long(), func_);
+        } else {
+            const auto lay = ctx_->long_layout(sizeof(tuple_t), MODE == 1 ? sizeof(RR) : (MODE == 2 ? 1 : 0));
+            const size_t lds = (gpu::BLOCK_THREADS / gpu::WAVE) * lay.first;
+            if (lds > 64 * 1024) gpu::failwith("keyed GPU operator: tuple type too large for the LDS staging buffers");
+            const unsigned lgrid =
+                (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / gpu::KEYED_LONG_RUN / (gpu::BLOCK_THREADS / gpu::WAVE) + 1));
+            hipLaunchKernelGGL((gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>), dim3(lgrid), dim3(gpu::BLOCK_THREADS), lds, s, d->header(),
+                               d->template data<tuple_t>(), out, flags, sorted.keys, sorted.vals, ctx_->states(), ctx_->state_size(),
+                               ctx_->long_heads(), ctx_->n_long(), lay.second, lay.first, func_);
+        }
         this->num_kernels_ += 2;
     }
 
