@@ -90,6 +90,20 @@ struct Gen {
     }
 };
 
+// source replica r of `stride` emits elements r, r + stride, r + 2 stride ... of a materialised stream: every lane is in
+// timestamp order, the lanes overlap in time
+struct StridedGen {
+    const vector<tuple_t>* st;
+    size_t stride;
+    size_t pos = (size_t)-1;
+    bool operator()(tuple_t& t, RuntimeContext& rc) {
+        if (pos == (size_t)-1) pos = rc.getReplicaIndex();
+        t = (*st)[pos];
+        pos += stride;
+        return pos < st->size();
+    }
+};
+
 static vector<tuple_t> materialize(size_t n, size_t keys) {
     Gen g(n, keys);
     vector<tuple_t> v;
@@ -130,7 +144,9 @@ int main(int argc, char** argv) {
         for (auto& kv : per) {
             const auto& v = kv.second;
             for (size_t w = 0; w * slide < v.size(); w++) {
-                for (size_t i = w * slide; i < min(v.size(), w * slide + win); i++) exp_c_sum += v[i];
+                // weighted by the window number: WHICH tuples fall into which window matters (a plain sum of all windows would
+                // hardly notice tuples of a key arriving in another order)
+                for (size_t i = w * slide; i < min(v.size(), w * slide + win); i++) exp_c_sum += v[i] * (long)(w % 7 + 1);
                 exp_c_cnt++;
             }
         }
@@ -224,7 +240,7 @@ int main(int argc, char** argv) {
             long sum = 0, cnt = 0;
             Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
                             if (o) {
-                                sum += o->value;
+                                sum += o->value * (long)(o->id % 7 + 1);
                                 cnt++;
                             }
                         }).withParallelism(1).build();
@@ -378,6 +394,85 @@ int main(int argc, char** argv) {
         cout << "G device split/merge par=" << p0 << "," << p1 << "," << p2 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << e_sum
              << " " << e_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
         failures += !ok;
+    }
+    // ---- I: DETERMINISTIC graphs on batch edges: 4 source lanes that overlap in time feed keyed GPU operators, whose device
+    //      KeyBy endpoint merges the lanes in timestamp order (the watermark rule on batches); the results are those of the
+    //      sequential stream whatever the parallelism ----
+    for (size_t run = 0; run < runs; run++) {
+        const size_t p1 = (size_t)dp(rng), p2 = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        {
+            PipeGraph g("keyed_i1", Mode::DETERMINISTIC);
+            auto src = BatchSource_Builder(StridedGen{&stream, 4}).withName("lanes").withParallelism(4).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto kff = KeyFFATGPU_Builder(Lift_GPU(), Comb_GPU()).withCBWindows(win, slide).withName("kff").withParallelism(p1).withMaxKeys(keys)
+                           .withOutputCapacity(1 << 16).build_unique();
+            mp.add(*kff);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
+                            if (o) {
+                                sum += o->value * (long)(o->id % 7 + 1);
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_c_sum && cnt == exp_c_cnt);
+            cout << "I deterministic windows par=" << p1 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << exp_c_sum << " "
+                 << exp_c_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        {
+            // a keyed in-place map alone: every tuple must carry the running sum its key had at that point of the SEQUENTIAL stream
+            vector<int64_t> exp_val(stream.size());
+            {
+                map<size_t, int64_t> acc;
+                for (size_t i = 0; i < stream.size(); i++) exp_val[i] = (acc[stream[i].key] += stream[i].value);
+            }
+            PipeGraph g("keyed_i3", Mode::DETERMINISTIC);
+            auto src = BatchSource_Builder(StridedGen{&stream, 4}).withName("lanes").withParallelism(4).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto map = MapGPU_Builder(RunningSum()).withName("kmap").withParallelism(p1).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*map);
+            long wrong = 0, cnt = 0, first_wrong = -1;
+            Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                            if (o) {
+                                if (o->value != exp_val[o->id]) {
+                                    if (wrong == 0) first_wrong = (long)o->id;
+                                    wrong++;
+                                }
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (wrong == 0 && cnt == (long)n);
+            cout << "I deterministic map par=" << p1 << " batch=" << batch << " wrong " << wrong << " (first at " << first_wrong << ") cnt " << cnt
+                 << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        {
+            PipeGraph g("keyed_i2", Mode::DETERMINISTIC);
+            auto src = BatchSource_Builder(StridedGen{&stream, 4}).withName("lanes").withParallelism(4).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto map = MapGPU_Builder(RunningSumOut()).withName("kmap").withParallelism(p1).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*map);
+            auto fil = FilterGPU_Builder(EveryThirdOut()).withName("kfilter").withParallelism(p2).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*fil);
+            long sum = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<output_t>& o) {
+                            if (o) {
+                                sum += o->value;
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (sum == exp_b_sum && cnt == exp_b_cnt);
+            cout << "I deterministic map+filter par=" << p1 << "," << p2 << " batch=" << batch << " sum " << sum << " cnt " << cnt << " (expected " << exp_b_sum
+                 << " " << exp_b_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
     }
     // ---- E (whenever 2+ GPUs are visible; WF_SKIP_MULTI_GPU=1 opts out): scenario B with the replicas of the two keyed
     //      operators placed on different GPUs; the sub-batches of the device KeyBy cross GPUs with peer copies ----

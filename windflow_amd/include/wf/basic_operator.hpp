@@ -99,6 +99,10 @@ public:
     virtual std::function<rt::Node*(edge_kind_t from)> output_adapter_factory() const { return nullptr; }
     // after a nested window operator the next operator must shuffle (A.12)
     virtual bool forces_shuffle_after() const { return false; }
+    // DETERMINISTIC graphs: true if the operator itself merges the batch lanes that feed it in timestamp order (keyed GPU
+    // operators do, through the device KeyBy endpoint); otherwise batches coming from a different number of lanes are
+    // turned back into tuples so that the ordering nodes of the tuple world apply
+    virtual bool merges_batch_lanes_in_order() const { return false; }
     // statistics of every replica (filled at the end of the run)
     virtual std::vector<Stats_Record> get_StatsRecords() const {
         std::lock_guard<std::mutex> l(hub_->m);

@@ -62,6 +62,11 @@ struct ExchangeConfig {
     // batch has waited this long: under load the rounds are fat (few large transfers and kernels), a lone batch is delayed by
     // at most this much
     uint64_t linger_us = 300;
+    // DETERMINISTIC graphs (one rank): the endpoint is the ordering point of the batch lanes.  Every producer lane is in
+    // timestamp order; the endpoint releases, per output lane, the tuples whose timestamp is <= the least of the producers'
+    // latest watermarks, merged in timestamp order (ties: producer, then position) - the low-watermark rule of the tuple
+    // world's ordering nodes (ordering_node.hpp) applied to batches.
+    bool deterministic = false;
 };
 
 // counters of one rank's endpoint, readable after the run (Exchange_GPU::stats())
@@ -77,6 +82,7 @@ struct ExchangeStats {
 // What a partition lane hands to the rank's endpoint
 struct ExchangeBundle {
     uint64_t arrived_us = 0;                // when the endpoint got it
+    size_t consumed[dist::MAX_LANES] = {};  // deterministic mode: tuples of every lane segment already released
     gpu::Batch* packed = nullptr;           // the batch grouped by destination (rank, lane)
     volatile uint32_t* offsets = nullptr;   // pinned: world * lanes + 1 offsets into `packed`, valid once packed->ready has fired
     gpu::Batch* passthrough = nullptr;      // one rank, one lane: the batch itself
@@ -162,6 +168,37 @@ private:
     std::vector<Slot> slots_;
     size_t next_ = 0;
 };
+// ---- deterministic merge (ExchangeConfig::deterministic) ----
+// thread per segment: how many tuples of a timestamp-ordered segment have ts <= W
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS) det_count_le_kernel(const SegCopy* segs, uint32_t n_segs, uint64_t W, volatile uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_segs) return;
+    const T* seg = static_cast<const T*>(segs[i].src);
+    uint32_t lo = 0, hi = (uint32_t)segs[i].count;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((uint64_t)std::get<2>(seg[mid].getControlFields()) <= W)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[i] = lo;
+}
+// sort keys of one 32-bit half of (ts - base); perm == nullptr: identity
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    det_keys_kernel(const T* work, uint32_t n, uint64_t base, int shift, const uint32_t* perm, uint32_t* keys, uint32_t* idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t src = perm ? perm[i] : i;
+        keys[i] = (uint32_t)((((uint64_t)std::get<2>(work[src].getControlFields())) - base) >> shift);
+        idx[i] = src;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS) det_gather_kernel(const T* work, const uint32_t* perm, T* out, uint32_t first, uint32_t count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) out[i] = work[perm[first + i]];
+}
 }  // namespace gpu
 
 // ---- stage 1: partition lanes (parallel) ------------------------------------------------------
@@ -169,8 +206,9 @@ template <typename tuple_t>
 class ExchangePart_Node : public GPU_Replica<tuple_t> {
 public:
     ExchangePart_Node(int world, size_t out_lanes, GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx,
-                      meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
-        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub)), world_(world), lanes_(out_lanes) {}
+                      meta::closing_func_t closing, std::shared_ptr<StatsHub> hub, bool always_pack = false)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub)), world_(world), lanes_(out_lanes),
+          always_pack_(always_pack) {}
     ~ExchangePart_Node() override {
         for (auto& kv : mirrors_) (void)hipHostFree((void*)kv.second);
     }
@@ -179,7 +217,7 @@ protected:
     void gpu_init() override {
         // a packed slab is held until its round has been merged (or, for a lone batch, until the peers have read it)
         const size_t slabs = std::max<size_t>(3, this->cfg_.pool_slabs) + (world_ > 1 ? dist::ControlBoard::DEPTH : 2);
-        if (world_ > 1 || lanes_ > 1) part_.reset(new gpu::BatchPartitioner<tuple_t>(1, this->cfg_.gpu_id, slabs));
+        if (world_ > 1 || lanes_ > 1 || always_pack_) part_.reset(new gpu::BatchPartitioner<tuple_t>(1, this->cfg_.gpu_id, slabs + (always_pack_ ? 8 : 0)));
     }
     void process_device(gpu::Batch* d) override {
         gpu::TraceRange trace("wf:exchange_partition");
@@ -211,6 +249,7 @@ private:
     }
     int world_;
     size_t lanes_;
+    bool always_pack_;
     std::unique_ptr<gpu::BatchPartitioner<tuple_t>> part_;
     std::unordered_map<gpu::Batch*, volatile uint32_t*> mirrors_;
 };
@@ -226,6 +265,8 @@ public:
         if (!xstats_) xstats_ = std::make_shared<ExchangeStats>();
         if (world() > dist::MAX_WORLD) gpu::failwith("Exchange_GPU: world size above MAX_WORLD");
         if (xcfg_.out_lanes == 0 || xcfg_.out_lanes > (size_t)dist::MAX_LANES) gpu::failwith("Exchange_GPU: between 1 and 16 output lanes");
+        if (xcfg_.deterministic && world() > 1)
+            gpu::failwith("Exchange_GPU: DETERMINISTIC graphs are ordered inside one rank only (the watermark rule needs every producer of a key)");
         cfg_.gpu_id = cfg.device_for(0);
     }
     void svc_init() override {
@@ -239,13 +280,23 @@ public:
         tables_.reset(new gpu::SegTables());
         last_round_us_ = start_us_ = xstats_->start_us = current_time_usecs();
     }
-    void svc(void* msg, int) override {
+    void svc(void* msg, int channel) override {
         auto* b = static_cast<ExchangeBundle*>(msg);
         b->arrived_us = current_time_usecs();
+        if (xcfg_.deterministic) {
+            det_arrive(b, channel);
+            return;
+        }
         pending_.push_back(b);
         pump();
     }
-    bool wants_idle() const override { return true; }
+    void eosnotify(int channel) override {
+        if (!xcfg_.deterministic || !stream_) return;
+        det_init();
+        det_ended_[(size_t)channel] = true;
+        det_release(false);
+    }
+    bool wants_idle() const override { return !xcfg_.deterministic; }
     void on_idle() override {
         if (!finished_) pump();
     }
@@ -253,6 +304,12 @@ public:
         // end of my stream: keep answering rounds until everybody is done
         done_ = true;
         if (!stream_) return;  // never started
+        if (xcfg_.deterministic) {
+            det_init();
+            det_release(true);
+            finished_ = true;
+            return;
+        }
         while (!finished_) {
             if (!pump()) std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
@@ -264,6 +321,10 @@ public:
     }
     void svc_end() override {
         if (stream_) stream_->sync();
+        if (det_counts_) (void)hipHostFree((void*)det_counts_);
+        if (det_segs_) (void)hipHostFree(det_segs_);
+        det_counts_ = nullptr;
+        det_segs_ = nullptr;
         tables_.reset();
         if (xstats_) xstats_->elapsed_us = current_time_usecs() - start_us_;
         Replica_Base::svc_end();
@@ -582,6 +643,191 @@ private:
         return progress;
     }
 
+    // ---- deterministic mode ------------------------------------------------------------------------------------
+    void det_init() {
+        if (!det_q_.empty()) return;
+        const size_t n = std::max<size_t>(num_in(), 1);
+        det_q_.resize(n);
+        det_wm_.assign(n, 0);
+        det_seen_.assign(n, false);
+        det_ended_.assign(n, false);
+        WF_HIP_CHECK(hipHostMalloc((void**)&det_counts_, DET_MAX_SEGS * sizeof(uint32_t), hipHostMallocDefault));
+        WF_HIP_CHECK(hipHostMalloc((void**)&det_segs_, DET_MAX_SEGS * sizeof(gpu::SegCopy), hipHostMallocDefault));
+        det_n_dev_.resize(1);
+    }
+    void det_arrive(ExchangeBundle* b, int channel) {
+        det_init();
+        const size_t c = (size_t)channel;
+        if (c >= det_q_.size()) gpu::failwith("Exchange_GPU: unexpected input channel");
+        my_cap_ = std::max(my_cap_, b->capacity);
+        det_q_[c].push_back(b);
+        det_wm_[c] = std::max(det_wm_[c], b->hdr.watermark);
+        det_seen_[c] = true;
+        det_release(false);
+    }
+    // release what the watermark rule allows (everything at end of stream)
+    void det_release(bool final) {
+        const size_t L = xcfg_.out_lanes;
+        hipStream_t s = stream_->get();
+        uint64_t W = UINT64_MAX;
+        bool any_open = false;
+        for (size_t c = 0; c < det_q_.size(); c++) {
+            if (det_ended_[c]) continue;
+            any_open = true;
+            if (!det_seen_[c]) return;  // a producer that has said nothing yet holds everything back
+            W = std::min(W, det_wm_[c]);
+        }
+        if (final || !any_open) W = UINT64_MAX;
+        if (W != UINT64_MAX && det_released_once_ && W <= det_last_w_) return;  // nothing new can be released
+        // the (bundle, lane) segments not yet released; those of a bundle that may hold later tuples are cut by a binary search
+        struct Piece {
+            ExchangeBundle* b;
+            size_t lane, off, len, take;
+            int probe;  // index in the probe table, -1: the whole piece goes
+        };
+        std::vector<Piece> pieces;
+        uint32_t n_probe = 0;
+        uint64_t hi_ts = det_last_w_;
+        for (auto& q : det_q_)
+            for (ExchangeBundle* b : q) {
+                b->packed->ready.host_sync();  // the offsets are on the host from here on
+                // watermark = what the producer claims to have delivered completely; reserved[2] (when set) = greatest timestamp
+                // the batch may hold, for batches that claim less than they carry (a release cut into several batches)
+                const uint64_t upper = b->hdr.reserved[2] != 0 ? b->hdr.reserved[2] : b->hdr.watermark;
+                const bool whole = upper <= W;
+                for (size_t l = 0; l < L; l++) {
+                    const size_t lo = b->offsets[l] + b->consumed[l], end = b->offsets[l + 1];
+                    if (lo >= end) continue;
+                    Piece pc{b, l, lo, end - lo, end - lo, -1};
+                    if (!whole) {
+                        if (n_probe >= DET_MAX_SEGS) gpu::failwith("Exchange_GPU: too many pending segments in deterministic mode");
+                        det_segs_[n_probe] = gpu::SegCopy{b->packed->template data<tuple_t>() + lo, nullptr, end - lo};
+                        pc.probe = (int)n_probe++;
+                    }
+                    pieces.push_back(pc);
+                }
+                hi_ts = std::max(hi_ts, std::min(W, upper));
+            }
+        if (n_probe > 0) {
+            hipLaunchKernelGGL((gpu::det_count_le_kernel<tuple_t>), dim3((n_probe + gpu::BLOCK_THREADS - 1) / gpu::BLOCK_THREADS), dim3(gpu::BLOCK_THREADS), 0, s,
+                               det_segs_, n_probe, W, det_counts_);
+            WF_HIP_CHECK(hipStreamSynchronize(s));
+            for (Piece& pc : pieces)
+                if (pc.probe >= 0) pc.take = det_counts_[pc.probe];
+        }
+        // per lane: concatenate the released pieces, sort them by timestamp (stable: ties keep producer, position order), cut
+        // the result into lane batches
+        uint64_t step_out = 0;
+        std::vector<ExchangeBundle*> finished_bundles;
+        for (auto& q : det_q_)
+            while (!q.empty()) {
+                ExchangeBundle* b = q.front();
+                bool all = true;
+                for (size_t l = 0; l < L; l++) {
+                    size_t take = 0;
+                    for (const Piece& pc : pieces)
+                        if (pc.b == b && pc.lane == l) take = pc.take;
+                    if (b->offsets[l] + b->consumed[l] + take < b->offsets[l + 1]) all = false;
+                }
+                if (!all) break;
+                if (b->hdr.reserved[0] != 0) note_local_punctuation(b->hdr.reserved[0]);
+                finished_bundles.push_back(b);
+                q.pop_front();
+            }
+        step_out = take_global_step(local_step_done_);
+        if (lane_cap_ == 0) {
+            const size_t cap = std::max<size_t>(my_cap_, 1);
+            lane_cap_ = cap;
+            lane_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(tuple_t), lane_cap_, std::max<size_t>(cfg_.pool_slabs, 3) * L));
+        }
+        const uint64_t base = det_last_w_;
+        for (size_t l = 0; l < L; l++) {
+            size_t n = 0;
+            for (const Piece& pc : pieces)
+                if (pc.lane == l) n += pc.take;
+            // a lane that receives nothing still learns the new watermark (an empty batch): the operator behind it is a
+            // producer of the next ordering point, which would otherwise wait for it for ever
+            if (n == 0 && step_out == 0 && hi_ts <= base) continue;
+            if (n > UINT32_MAX) gpu::failwith("Exchange_GPU: too many tuples in one deterministic release");
+            const uint32_t* perm = nullptr;
+            if (n > 0) {
+                if (det_work_.size() < n) {
+                    WF_HIP_CHECK(hipStreamSynchronize(s));  // the old buffers may still be read
+                    det_work_.resize(n + n / 2);
+                    det_keys_.resize(n + n / 2);
+                    det_idx_.resize(n + n / 2);
+                }
+                tables_->clear();
+                size_t fill = 0;
+                for (const Piece& pc : pieces) {
+                    if (pc.lane != l || pc.take == 0) continue;
+                    tables_->segs.push_back({pc.b->packed->template data<tuple_t>() + pc.off, det_work_.data() + fill, pc.take});
+                    fill += pc.take;
+                }
+                tables_->template launch<tuple_t>(s);
+                const uint32_t n32 = (uint32_t)n;
+                WF_HIP_CHECK(hipMemcpyAsync(det_n_dev_.data(), &n32, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                const uint64_t range = hi_ts >= base ? hi_ts - base : 0;
+                int bits = 1;
+                while (bits < 64 && (range >> bits) != 0) bits++;
+                const unsigned grid = gpu::grid_for(n);
+                hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 0,
+                                   (const uint32_t*)nullptr, det_keys_.data(), det_idx_.data());
+                auto sorted = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), n, std::min(bits, 32), s);
+                if (bits > 32) {  // LSD: a second stable sort on the high half
+                    if (det_keys2_.size() < det_keys_.size()) {
+                        det_keys2_.resize(det_keys_.size());
+                        det_idx2_.resize(det_keys_.size());
+                    }
+                    hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 32,
+                                       (const uint32_t*)sorted.vals, det_keys2_.data(), det_idx2_.data());
+                    sorted = det_sorter2_.sort(det_keys2_.data(), det_idx2_.data(), det_n_dev_.data(), n, bits - 32, s);
+                }
+                perm = sorted.vals;
+            }
+            size_t done = 0;
+            do {
+                const size_t cnt = std::min(n - done, lane_cap_);
+                gpu::Batch* out = lane_pool_->acquire(s);
+                out->host_hdr = gpu::BatchHeader{};
+                out->host_hdr.count = (uint32_t)cnt;
+                out->host_hdr.source_id = (uint32_t)rank();
+                // only the last batch of a release may claim the new watermark: the ones before it hold a part of the release
+                const bool last = done + cnt == n;
+                out->host_hdr.watermark = last ? hi_ts : base;
+                out->host_hdr.reserved[2] = last ? 0 : hi_ts;
+                out->host_hdr.first_seq = seq_;
+                out->host_hdr.reserved[0] = last ? step_out : 0;
+                out->count_on_host = true;
+                WF_HIP_CHECK(hipMemcpyAsync(out->slab, &out->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, s));
+                if (cnt > 0)
+                    hipLaunchKernelGGL((gpu::det_gather_kernel<tuple_t>), dim3(gpu::grid_for(cnt)), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), perm,
+                                       out->template data<tuple_t>(), (uint32_t)done, (uint32_t)cnt);
+                // the header copy reads host_hdr of this slab and the sort reuses its buffers for the next lane: settle first
+                WF_HIP_CHECK(hipStreamSynchronize(s));
+                out->ready.record(s);
+                emit_to(out, l);
+                xstats_->lane_batches++;
+                seq_ += cnt;
+                done += cnt;
+            } while (done < n);
+            xstats_->tuples_received += n;
+        }
+        for (Piece& pc : pieces) pc.b->consumed[pc.lane] += pc.take;
+        for (ExchangeBundle* b : finished_bundles) {
+            b->packed->release(s);
+            delete b;
+            xstats_->bundles++;
+        }
+        xstats_->rounds++;
+        if (W != UINT64_MAX) {
+            det_last_w_ = W;
+            det_released_once_ = true;
+        } else {
+            det_last_w_ = hi_ts;
+        }
+    }
+
     gpu::Batch* acquire(std::unique_ptr<gpu::BatchPool>& pool, size_t& pool_cap, size_t need, size_t slabs) {
         if (!pool || pool_cap < need) {
             // batches of the old pool may still be in flight: keep it alive until the end
@@ -630,6 +876,18 @@ private:
     bool rank_done_[dist::MAX_WORLD] = {};
     std::map<uint64_t, size_t> punct_seen_;
     bool done_ = false, finished_ = false;
+    // deterministic mode
+    static constexpr uint32_t DET_MAX_SEGS = 16384;
+    std::vector<std::deque<ExchangeBundle*>> det_q_;  // per producer channel, in arrival order
+    std::vector<uint64_t> det_wm_;
+    std::vector<bool> det_seen_, det_ended_;
+    uint64_t det_last_w_ = 0;
+    bool det_released_once_ = false;
+    volatile uint32_t* det_counts_ = nullptr;
+    gpu::SegCopy* det_segs_ = nullptr;
+    gpu::DeviceBuffer<tuple_t> det_work_;
+    gpu::DeviceBuffer<uint32_t> det_keys_, det_idx_, det_keys2_, det_idx2_, det_n_dev_;
+    gpu::RadixSorter det_sorter_, det_sorter2_;
 };
 
 // The two stages in front of a consumer with `lanes` replicas: (1) one packing node per producer, fused onto it;
@@ -648,7 +906,7 @@ inline std::vector<StageSpec> exchange_stages(rt::Graph& g, std::shared_ptr<dist
     const size_t lanes = xcfg.out_lanes;
     a.per_producer = [=](size_t i, size_t n) -> rt::Node* {
         *n_producers = n;
-        return new ExchangePart_Node<tuple_t>(world, lanes, cfg, in_kind, name + "_partition", n, i, nullptr, hub);
+        return new ExchangePart_Node<tuple_t>(world, lanes, cfg, in_kind, name + "_partition", n, i, nullptr, hub, xcfg.deterministic);
     };
     StageSpec b;
     b.name = name;
@@ -665,9 +923,10 @@ inline std::vector<StageSpec> exchange_stages(rt::Graph& g, std::shared_ptr<dist
 // KeyBy inside one GPU for a keyed operator with `lanes` replicas (see the top of this file)
 template <typename tuple_t>
 inline std::vector<StageSpec> device_keyby_stages(rt::Graph& g, const std::string& op_name, const GPUConfig& cfg, size_t lanes, edge_kind_t in_kind,
-                                                  std::shared_ptr<StatsHub> hub) {
+                                                  std::shared_ptr<StatsHub> hub, bool deterministic = false) {
     ExchangeConfig xcfg;
     xcfg.out_lanes = lanes;
+    xcfg.deterministic = deterministic;
     return exchange_stages<tuple_t>(g, nullptr, op_name + "_keyby", cfg, xcfg, in_kind, std::move(hub));
 }
 

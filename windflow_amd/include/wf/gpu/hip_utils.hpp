@@ -336,7 +336,8 @@ struct alignas(64) BatchHeader {
     uint64_t watermark;   // greatest timestamp contained (low-watermark propagation)
     uint64_t first_seq;   // sequence number of the first tuple (per producer)
     uint64_t created_ns;  // host clock when the batch was opened (latency accounting)
-    uint64_t reserved[4];
+    uint64_t reserved[4];  // [0] step punctuation (Batch_Source), [1] marker batch flag, [2] upper bound of the timestamps when the
+                           // batch holds more than its watermark claims (deterministic merge, dist/exchange_nodes.hpp)
 };
 static_assert(sizeof(BatchHeader) == 64, "BatchHeader must be 64 bytes");
 

@@ -1089,19 +1089,21 @@ public:
     // per-replica device counters, valid after the end of the run
     std::vector<gpu::FFATCounters> getDeviceCounters() const { return *counters_; }
 
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
+    bool merges_batch_lanes_in_order() const override { return !wcfg_.lanes_are_key_disjoint; }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode mode) override {
         StageSpec s;
         s.name = name_;
         const size_t N = par_;
         const edge_kind_t kind = *kind_;
-        if (kind != EDGE_TUPLE && !wcfg_.lanes_are_key_disjoint && N > 1) {
+        const bool det = mode == Mode::DETERMINISTIC;
+        if (kind != EDGE_TUPLE && !wcfg_.lanes_are_key_disjoint && (N > 1 || det)) {
             // device KeyBy (dist/exchange_nodes.hpp): every producer packs its batches by replica, one endpoint thread merges the
             // packed slabs of all producers into one device batch per replica
             *kind_ = EDGE_DEVICE_BATCH;
             GPUConfig kcfg;
             kcfg.gpu_id = gpu_id_;
             kcfg.pool_slabs = slabs_;
-            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, kcfg, N, kind, hub_);
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, kcfg, N, kind, hub_, det);
             s.replicas = factory_(g);
             s.routing = FORWARD;  // lane i of the endpoint -> replica i
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };

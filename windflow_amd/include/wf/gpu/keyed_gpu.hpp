@@ -533,7 +533,8 @@ public:
     void set_input_kind(edge_kind_t k) override { *kind_ = k; }
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(cfg_.pool_slabs); }
 
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
+    bool merges_batch_lanes_in_order() const override { return !kcfg_.lanes_are_key_disjoint; }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode mode) override {
         StageSpec s;
         s.name = name_;
         const size_t N = par_;
@@ -550,7 +551,7 @@ public:
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
         } else {
             // device KeyBy (dist/exchange_nodes.hpp): producers pack their batches by replica, one endpoint merges them per replica
-            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_);
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_, mode == Mode::DETERMINISTIC);
             s.routing = FORWARD;
             s.replicas = factory_(g, EDGE_DEVICE_BATCH);
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };

@@ -59,8 +59,9 @@ public:
 
     edge_kind_t kind = EDGE_TUPLE;
     size_t slabs() const { return cfg_.pool_slabs; }
+    bool key_disjoint() const { return opt_.lanes_are_key_disjoint; }
 
-    std::vector<StageSpec> build(rt::Graph& g, std::shared_ptr<StatsHub> hub_ = nullptr) {
+    std::vector<StageSpec> build(rt::Graph& g, std::shared_ptr<StatsHub> hub_ = nullptr, bool deterministic = false) {
         StageSpec s;
         s.name = name_;
         const size_t N = par_;
@@ -74,7 +75,7 @@ public:
         gpu::WinGPUOptions opt = opt_;
         // batches carry no per-key renumbering stage in front of them: count-based windows count arrivals on the device
         if (kind != EDGE_TUPLE && type_ == CB) opt.renumber = true;
-        const bool keyby = kind != EDGE_TUPLE && !opt.lanes_are_key_disjoint && N > 1;
+        const bool keyby = kind != EDGE_TUPLE && !opt.lanes_are_key_disjoint && (N > 1 || deterministic);
         const edge_kind_t node_kind = keyby ? EDGE_DEVICE_BATCH : kind;
         for (size_t i = 0; i < N; i++) s.replicas.push_back(g.adopt(factory_(p, opt, node_kind, N, i)));
         if (kind == EDGE_TUPLE) {
@@ -84,7 +85,7 @@ public:
             s.make_ordering = window_ordering<tuple_t>(type_, name_);
         } else if (keyby) {
             // device KeyBy (dist/exchange_nodes.hpp): producers pack their batches by replica, one endpoint merges them per replica
-            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_);
+            std::vector<StageSpec> stages = device_keyby_stages<tuple_t>(g, name_, cfg_, N, kind, hub_, deterministic);
             s.routing = FORWARD;
             s.make_emitter = [N](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<tuple_t>(N), N); };
             stages.push_back(s);
@@ -138,6 +139,7 @@ public:
                  opt_level_t opt_level = LEVEL2)
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, std::move(routing), opt_level) {}
     bool isGPUOperator() const override { return true; }
+    bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
     edge_kind_t output_kind() const override { return flat_ ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }
     void set_input_kind(edge_kind_t k) override {
@@ -146,7 +148,7 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
         return flat_ ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
     }
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return flat_ ? flat_->build(g, this->hub_) : base_t::build_stages(g, m); }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return flat_ ? flat_->build(g, this->hub_, m == Mode::DETERMINISTIC) : base_t::build_stages(g, m); }
     // per-replica device counters, valid after the end of the run
     std::vector<gpu::WinCounters> getDeviceCounters() const { return counters_ ? *counters_ : std::vector<gpu::WinCounters>(); }
 
@@ -186,6 +188,7 @@ public:
                  size_t num_replicas, std::string name, meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL2)
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, ordered, opt_level) {}
     bool isGPUOperator() const override { return true; }
+    bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
     edge_kind_t output_kind() const override { return batch_path() ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }
     void set_input_kind(edge_kind_t k) override {
@@ -194,7 +197,7 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
         return batch_path() ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
     }
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return batch_path() ? flat_->build(g, this->hub_) : base_t::build_stages(g, m); }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override { return batch_path() ? flat_->build(g, this->hub_, m == Mode::DETERMINISTIC) : base_t::build_stages(g, m); }
     std::vector<gpu::WinCounters> getDeviceCounters() const { return counters_ ? *counters_ : std::vector<gpu::WinCounters>(); }
 
 private:

@@ -385,6 +385,12 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         fatal_error("output type of the last operator in the MultiPipe does not match the input type of operator " + op.getName());
     rt::Graph& g = graph_->graph_;
     const Mode mode = graph_->mode_;
+    // DETERMINISTIC mode: batches of several lanes cannot simply be shuffled (lanes overlap in time).  Keyed GPU operators order
+    // them themselves; in front of anything else that is not fed lane by lane the batches become tuples again and the
+    // ordering nodes do their work.
+    if (mode == Mode::DETERMINISTIC && tail_kind_ != EDGE_TUPLE && !op.merges_batch_lanes_in_order() &&
+        (tails_.size() != op.getParallelism() || force_shuffle_ || fresh_from_split_ || op.getRoutingMode() != FORWARD))
+        adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
     // edge negotiation: hand batches over when the operator can take them
     adapt_tails([&op](edge_kind_t k) { return op.accepts_input_kind(k); });
     op.set_input_kind(tail_kind_);
@@ -420,12 +426,9 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         } else if (direct) {
             for (size_t i = 0; i < n; i++) g.connect_queue(prev[i].node, prev[i].port, s.replicas[i]);
         } else {
-            // heads of the new threads: [ordering ->] replica.  Ordering nodes merge individual tuples: a
-            // shuffle of batches cannot be made deterministic (batches of different lanes overlap in time)
+            // heads of the new threads: [ordering ->] replica.  Ordering nodes merge individual tuples (batch edges reach this
+            // point in DETERMINISTIC mode only when the operator orders its lanes itself, see the top of this function)
             const bool batch_edge = !s.internal && tail_kind_ != EDGE_TUPLE;
-            if (batch_edge && mode == Mode::DETERMINISTIC && prev.size() > 1)
-                fatal_error("DETERMINISTIC mode: operator " + op.getName() + " would shuffle batches coming from " + std::to_string(prev.size()) +
-                            " lanes; give it the parallelism of its producer or run the PipeGraph in DEFAULT mode");
             std::vector<rt::Node*> heads(n);
             for (size_t i = 0; i < n; i++) {
                 rt::Node* ord = (s.make_ordering && !batch_edge) ? s.make_ordering(mode) : nullptr;
