@@ -48,10 +48,19 @@ tsan: tests/cpp/test_runtime.cpp $(HEADERS)
 	$(CXX) -O1 -g -std=c++17 -fsanitize=thread $(INC) $< -o tests/cpp/bin/test_runtime_tsan -pthread
 	WF_QUIET=1 tests/cpp/bin/test_runtime_tsan
 
+# AddressSanitizer + UndefinedBehaviorSanitizer builds of the CPU regression programs (host code only)
+ASAN_PROGS := test_runtime test_api_variants test_mp_windows test_graphs
+asan: $(HEADERS)
+	@mkdir -p tests/cpp/bin
+	for p in $(ASAN_PROGS); do $(CXX) -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
+	    $(INC) tests/cpp/$$p.cpp -o tests/cpp/bin/$${p}_asan -pthread || exit 1; done
+	WF_QUIET=1 tests/cpp/bin/test_runtime_asan && WF_QUIET=1 tests/cpp/bin/test_api_variants_asan && \
+	WF_QUIET=1 tests/cpp/bin/test_mp_windows_asan -r 1 -l 300 -k 3 -w 9 -s 3 && WF_QUIET=1 tests/cpp/bin/test_graphs_asan -r 1
+
 check-cpu: cpu
 	WF_QUIET=1 tests/cpp/bin/test_runtime && WF_QUIET=1 tests/cpp/bin/test_api_variants && WF_QUIET=1 tests/cpp/bin/test_graphs -r 1
 
 clean:
 	rm -rf tests/cpp/bin apps/bin
 
-.PHONY: all cpu gpu tsan check-cpu clean
+.PHONY: all cpu gpu tsan asan check-cpu clean

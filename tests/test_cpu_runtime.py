@@ -116,6 +116,22 @@ def test_runtime_tsan():
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("prog,args", [("test_runtime", []), ("test_api_variants", []), ("test_mp_windows", ["-r", "1", "-l", "300", "-k", "3", "-w", "9", "-s", "3"]),
+                                       ("test_graphs", ["-r", "1"])])
+def test_address_and_undefined_behaviour_sanitizers(prog, args):
+    """The CPU regression programs under AddressSanitizer + UndefinedBehaviorSanitizer (host code only; `make asan` runs the same)."""
+    src = os.path.join(HERE, "cpp", prog + ".cpp")
+    exe = os.path.join(BIN, prog + "_asan")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(BIN, exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                               "-fno-omit-frame-pointer", "-I" + wfbuild.INCLUDE, "-I" + os.path.join(HERE, "cpp"), src, "-o", exe, "-pthread"])
+    env = dict(os.environ, WF_QUIET="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)  # the sanitizer runtime must come first in the library list
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout[-1500:] + r.stderr[-3000:])
+
+
 def test_api_variants():
     """Every functor signature accepted by the builders (plain / rich, Source loop mode, Filter modes, Sink forms,
     window function flavours, closing functions, LocalStorage, custom KeyBy routing)."""

@@ -33,6 +33,21 @@ def test_map_inplace_matches_torch(ext, n):
     assert torch.equal(out[:, 4], t[:, 4])
 
 
+@pytest.mark.parametrize("n", [1, 64, 1000, 1025, 100_000, 1_000_003])
+def test_map_out_of_place_matches_torch(ext, n):
+    """K6 (gpu::map_kernel): tuple -> result of another type, batch header carried over"""
+    t = make_tuples(n)
+    d = t.cuda()
+    out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    assert ext.map_scale_out_of_place(d.data_ptr(), n, out.data_ptr(), 1.75) == n
+    torch.cuda.synchronize()
+    res = out.cpu()
+    assert torch.equal(res[:, :3], t[:, :3])
+    ref = t[:, 3].view(torch.float64) * 1.75 + t[:, 4].view(torch.float64)
+    assert torch.allclose(res[:, 3].view(torch.float64), ref, rtol=1e-15, atol=0)
+    assert torch.equal(d.cpu(), t), "the input batch must not change"
+
+
 @pytest.mark.parametrize("n", [0, 1, 64, 1023, 1024, 1025, 4096, 65_537, 1_000_003])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_filter_compact_matches_torch(ext, n, mode):

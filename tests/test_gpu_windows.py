@@ -429,3 +429,45 @@ def test_key_ffat_huge_runs_with_disorder_fall_back(ext):
     res_b, ctr_b = ext.key_ffat_run(t, 1000, 250, 0, True, 64, 1024, 1 << 18)
     assert ctr_a["dropped"] == ctr_b["dropped"] and ctr_a["dropped"] > 0
     assert unpack(res_a) == unpack(res_b)
+
+
+# ---- FlatFAT_GPU: one whole tree processed by many threads (reference: wf/flatfat_gpu.hpp) ------------------------------
+
+def _fold(w, mode):
+    return float(np.sum(w)) if mode == 0 else (float(w[-1]) if mode == 1 else float(w[0]))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])  # sum / newest wins / oldest wins: the last two are not commutative
+@pytest.mark.parametrize("cap,first,step,rounds,win,slide", [
+    (100, 60, 30, 12, 20, 5),        # a tree smaller than one 512-leaf tile; the circular buffer wraps several times
+    (512, 512, 128, 9, 64, 16),      # exactly one tile, always full
+    (3000, 1000, 700, 11, 300, 50),  # 4096 leaves: 8 tiles + the top of the tree, dirty ranges that wrap around
+    (5000, 4000, 1, 40, 1000, 250),  # single-leaf updates of a large tree
+])
+def test_flatfat_gpu_matches_a_plain_fold(ext, mode, cap, first, step, rounds, win, slide):
+    rng = np.random.default_rng(cap + mode)
+    fat = ext.FlatFatGPU(cap, 4096, mode)
+    assert fat.capacity >= cap and fat.capacity & (fat.capacity - 1) == 0
+    live = list(rng.integers(-100, 100, first).astype(float))
+    ts0 = 1  # timestamps are the arrival numbers of the leaves
+    fat.build(live)
+
+    def check():
+        n_win = 0 if len(live) < win else (len(live) - win) // slide + 1
+        got = fat.results(n_win, win, slide)
+        assert len(got) == n_win
+        for w, (val, ts) in enumerate(got):
+            seg = live[w * slide:w * slide + win]
+            assert val == pytest.approx(_fold(seg, mode), abs=1e-9), (w, len(live))
+            assert ts == ts0 + w * slide + win - 1  # the newest leaf of the window
+
+    check()
+    for _ in range(rounds):
+        new = list(rng.integers(-100, 100, step).astype(float))
+        remove = max(0, len(live) + step - fat.capacity) if len(live) + step > fat.capacity else int(rng.integers(0, min(len(live), step) + 1))
+        fat.update(new, remove)
+        live = live[remove:] + new
+        ts0 += remove
+        assert fat.size == len(live)
+        check()
+    assert fat.kernels > 0

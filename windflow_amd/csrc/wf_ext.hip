@@ -56,6 +56,32 @@ static void map_scale_inplace(uintptr_t tuples, size_t n, double factor) {
     WF_HIP_CHECK(hipDeviceSynchronize());
 }
 
+// out-of-place map (K6, gpu::map_kernel) over n tuples: result = (key, id, ts, value*factor + aux); also copies the header
+struct ScaleToResult {
+    double factor;
+    __host__ __device__ void operator()(const tuple_t& t, result_t& r) const {
+        r.setControlFields(t.key, t.id, t.ts);
+        r.value = t.value * factor + t.aux;
+    }
+};
+static size_t map_scale_out_of_place(uintptr_t tuples, size_t n, uintptr_t results, double factor) {
+    check_ptr(tuples, "tuples");
+    check_ptr(results, "results");
+    gpu::DeviceBuffer<gpu::BatchHeader> hdr(2);
+    gpu::BatchHeader h{};
+    h.count = (uint32_t)n;
+    h.watermark = 77;
+    WF_HIP_CHECK(hipMemcpy(hdr.data(), &h, sizeof(h), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((gpu::map_kernel<tuple_t, result_t, ScaleToResult>), dim3(gpu::grid_for(std::max<size_t>(n, 1))), dim3(gpu::BLOCK_THREADS), 0, 0,
+                       hdr.data(), reinterpret_cast<const tuple_t*>(tuples), hdr.data() + 1, reinterpret_cast<result_t*>(results), ScaleToResult{factor});
+    WF_HIP_CHECK(hipGetLastError());
+    WF_HIP_CHECK(hipDeviceSynchronize());
+    gpu::BatchHeader out{};
+    WF_HIP_CHECK(hipMemcpy(&out, hdr.data() + 1, sizeof(out), hipMemcpyDeviceToHost));
+    if (out.watermark != 77) throw std::runtime_error("map_kernel did not copy the batch header");
+    return out.count;
+}
+
 // stable compaction of the tuples with value < threshold (mode 0) or even key (mode 1);
 // returns the number of survivors
 static size_t filter_compact(uintptr_t in, size_t n, uintptr_t out, int mode, double threshold) {
@@ -199,6 +225,45 @@ struct CombByMode {
     __host__ __device__ void operator()(const result_t& a, const result_t& b, result_t& out) const {
         out.value = mode == 0 ? a.value + b.value : (mode == 1 ? b.value : a.value);
     }
+};
+
+// FlatFAT_GPU driven from Python: one device-resident aggregator tree whose leaves are a circular buffer
+// (reference: wf/flatfat_gpu.hpp:251-434 build / update / getResults)
+class FlatFatSession {
+public:
+    FlatFatSession(size_t capacity, size_t max_windows, int comb_mode) : fat_(CombByMode{comb_mode}, capacity, max_windows, stream_.get()) {}
+    size_t capacity() const { return fat_.capacity(); }
+    size_t size() const { return fat_.size(); }
+    void build(const std::vector<double>& values) { fat_.build(leaves(values).data(), values.size()); }
+    void update(const std::vector<double>& values, size_t n_remove) { fat_.update(leaves(values).data(), values.size(), n_remove); }
+    // n_windows windows of `win` leaves sliding by `slide` from the oldest live leaf: (value, ts) per window
+    std::vector<std::pair<double, uint64_t>> results(size_t n_windows, size_t win, size_t slide) {
+        std::vector<result_t> stamped(n_windows);
+        for (size_t w = 0; w < n_windows; w++) stamped[w].setControlFields(7, w, 0);
+        fat_.computeResults(stamped.data(), n_windows, win, slide);
+        size_t n = 0;
+        const result_t* r = fat_.waitResults(n);
+        std::vector<std::pair<double, uint64_t>> out;
+        for (size_t w = 0; w < n; w++) {
+            if (r[w].key != 7 || r[w].id != w) throw std::runtime_error("FlatFAT_GPU lost the stamped control fields");
+            out.push_back({r[w].value, r[w].ts});
+        }
+        return out;
+    }
+    uint64_t kernels() const { return fat_.num_kernels(); }
+
+private:
+    std::vector<result_t> leaves(const std::vector<double>& values) {
+        std::vector<result_t> l(values.size());
+        for (size_t i = 0; i < values.size(); i++) {
+            l[i].setControlFields(7, 0, next_ts_++);
+            l[i].value = values[i];
+        }
+        return l;
+    }
+    gpu::Stream stream_;
+    gpu::FlatFAT_GPU<result_t, CombByMode> fat_;
+    uint64_t next_ts_ = 1;
 };
 
 static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::array::forcecast> tuples, uint64_t win, uint64_t slide,
@@ -959,6 +1024,15 @@ PYBIND11_MODULE(_C, m) {
     }, py::arg("device"), "PCI address (domain:bus:device.function) of a GPU, without creating a context on it");
     m.def("tuple_size", []() { return sizeof(tuple_t); });
     m.def("map_scale_inplace", &map_scale_inplace, py::arg("tuples"), py::arg("n"), py::arg("factor"));
+    m.def("map_scale_out_of_place", &map_scale_out_of_place, py::arg("tuples"), py::arg("n"), py::arg("results"), py::arg("factor"));
+    py::class_<FlatFatSession>(m, "FlatFatGPU")
+        .def(py::init<size_t, size_t, int>(), py::arg("capacity"), py::arg("max_windows"), py::arg("comb_mode") = 0)
+        .def_property_readonly("capacity", &FlatFatSession::capacity)
+        .def_property_readonly("size", &FlatFatSession::size)
+        .def_property_readonly("kernels", &FlatFatSession::kernels)
+        .def("build", &FlatFatSession::build)
+        .def("update", &FlatFatSession::update, py::arg("values"), py::arg("n_remove"))
+        .def("results", &FlatFatSession::results, py::arg("n_windows"), py::arg("win"), py::arg("slide"));
     m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
     m.def("key_ffat_run", &key_ffat_run, py::arg("tuples"), py::arg("win"), py::arg("slide"), py::arg("delay"), py::arg("time_based"),
           py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0, py::arg("comb_mode") = 0, py::arg("skip_gaps") = false);

@@ -146,11 +146,4 @@ inline win_engine_maker_t cpu_win_engine(F func, meta::closing_func_t closing, s
     };
 }
 
-// helper: window-engine replicas (role SEQ/PLQ/WLQ/MAP/REDUCE) for one farm stage
-template <typename in_t, typename out_t, typename F>
-inline rt::Node* make_win_seq(rt::Graph& g, F func, const WinParams& p, const std::string& name, size_t par, size_t idx,
-                              meta::closing_func_t closing, std::shared_ptr<StatsHub> hub) {
-    return g.adopt(new Win_Seq_Node<in_t, out_t, F>(func, p, name, par, idx, closing, std::move(hub)));
-}
-
 }  // namespace wf

@@ -7,12 +7,31 @@ __all__ = ["RUNTIME_ENV", "runtime_env", "read_stats_dump", "percentile"]
 
 # name -> meaning (defaults in parentheses)
 RUNTIME_ENV = {
+    # host runtime (include/wf/rt/config.hpp)
     "WF_QUEUE_CAPACITY": "slots of every inter-thread SPSC ring (2048)",
-    "WF_BLOCKING": "1: consumers sleep on a condition variable instead of spin/yield back-off (0)",
-    "WF_PIN_THREADS": "1: pin runtime threads to cores round-robin (0)",
+    "WF_BLOCKING": "1: a thread whose input rings are empty (or whose output ring is full) parks on a futex and is woken by its "
+                   "peer; 0: spin / yield / sleep back-off (0)",
+    "WF_PARK_TIMEOUT_US": "blocking mode: longest a parked thread sleeps before it looks again (2000)",
+    "WF_SPIN_ITERS": "back-off mode: polls before a thread starts yielding (64)",
+    "WF_SLEEP_US": "back-off mode: sleep between polls once yielding did not help (50)",
+    "WF_PIN_THREADS": "1: pin the runtime threads, one per CPU of the process's affinity mask (or of WF_PIN_CPUS) (0)",
+    "WF_PIN_CPUS": "CPU list to pin to, e.g. 0-15,64-79 (default: the process's affinity mask - bench.py gives every rank the "
+                   "CPUs of its GPU's NUMA node)",
     "WF_TRACE": "1: collect per-replica statistics and dump JSON + DOT at the end of the run (0)",
     "WF_LOG_DIR": "directory of the statistics dump (./log)",
     "WF_QUIET": "1: no banner on stdout (0)",
+    # device side (include/wf/gpu/hip_utils.hpp, the engines)
+    "WF_UPLOAD_STREAMS": "streams the host-to-device copies of a replica alternate over",
+    "WF_D2H_STREAMS": "own: every DeviceToHost adapter copies on its own stream; shared: on the producer's",
+    "WF_POOL_WAIT": "host | device: where a re-acquired slab's last use is waited for (host)",
+    "WF_EDGE_WAIT": "host | device: where a consumer waits for the event of a batch produced by another stream (device)",
+    "WF_EVENT_BLOCKING": "1: host waits on events sleep instead of spinning",
+    "WF_STREAM_REAP": "how often finished stream work is reaped",
+    "WF_HIP_GRAPHS": "1: Key_FFAT_GPU replays its per-batch launch sequence from a hipGraph (0: measured not to be faster)",
+    "WF_FFAT_HUGE": "0: never spread huge runs of a key over the chip (gpu/ffat_huge_gpu.hpp) (1)",
+    "WF_WIN_TILE": "0: non-incremental window engine without the LDS-tiled evaluation kernel (1)",
+    "WF_ROCTX": "1: roctx ranges around the operators' work (for rocprofv3 --marker-trace)",
+    "WF_SEGV_TRACE": "1: print a backtrace on SIGSEGV (debugging aid of the benchmark programs)",
 }
 
 
