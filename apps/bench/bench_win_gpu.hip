@@ -200,14 +200,16 @@ int main(int argc, char** argv) {
     if (op == "kf") {
         oper = KeyFarm_Builder(sum_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kf_gpu") {
-        oper = KeyFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).build_unique();
+        oper = KeyFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64).build_unique();
     } else if (op == "wf_gpu") {
-        oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).build_unique();
+        oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64)
+                   .build_unique();
     } else if (op == "pf_gpu") {
-        oper = PaneFarmGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas, 1).withBatch(batch).build_unique();
+        oper = PaneFarmGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas, 1).withBatch(batch)
+                   .withMaxKeys(keys_per_source + 64).build_unique();
     } else if (op == "wmr_gpu") {
         oper = WinMapReduceGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(std::max<size_t>(2, replicas), 1)
-                   .withBatch(batch).build_unique();
+                   .withBatch(batch).withMaxKeys(keys_per_source + 64).build_unique();
     } else if (op == "kff") {
         oper = KeyFFAT_Builder(lift_cpu, comb_cpu).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kff_gpu") {

@@ -49,10 +49,10 @@ static void run_rank(const DistOptions& d, std::shared_ptr<dist::Transport> tr, 
         scfg.gpu_id = device;
         split_gpu(*pipe, ysb::AdTypeSplit(), 2, scfg);
         MultiPipe& b0 = pipe->select(0);
-        b0.add(*filters[0]);
+        b0.chain(*filters[0]);
         b0.chain(*joins[0]);
         MultiPipe& b1 = pipe->select(1);
-        b1.add(*filters[1]);
+        b1.chain(*filters[1]);
         b1.chain(*joins[1]);
         pipe = &b0.merge(b1);
     } else {

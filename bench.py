@@ -47,6 +47,9 @@ def parse_args():
                         "stateless Map_GPU+Filter_GPU")
     p.add_argument("--ysb-period-us", type=int, default=1, help="ysb: event-time distance between two events of a source")
     p.add_argument("--ysb-delay-us", type=int, default=1000000, help="ysb: triggering delay of the windows (tolerated lag between sources)")
+    p.add_argument("--ysb-split-merge", action="store_true",
+                   help="ysb: split the events on the device by ad type into two filter+join branches and merge them again in front of the "
+                        "aggregation (the split/merge PipeGraph of BASELINE config 5)")
     p.add_argument("--sources", type=int, default=int(os.environ.get("WF_BENCH_SOURCES", "8")))
     p.add_argument("--batch", type=int, default=int(os.environ.get("WF_BENCH_BATCH", "0")),
                    help="tuples per batch; default 128 Ki with 4 batches in flight per lane (dp: the throughput plateau at half "
@@ -349,7 +352,7 @@ def main():
 
             transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
         pipe = ext.YsbPipeline(local_rank, args.sources, args.batch, args.ysb_period_us, args.ysb_delay_us, args.inflight,
-                               args.agg_replicas or 1, transport)
+                               args.agg_replicas or 1, transport, args.ysb_split_merge)
     else:
         raise SystemExit("unknown pipeline %r" % args.pipeline)
 
@@ -397,7 +400,8 @@ def main():
             "p50_latency_us": stats["latency_p50_us"],
             "config": {
                 "model": {"win_agg": "Key_FFAT_GPU keyed sliding-window sum",
-                          "ysb": "Yahoo Streaming Benchmark: Filter_GPU -> Map_GPU(join) -> Key_FFAT_GPU 10 s tumbling count per campaign",
+                          "ysb": "Yahoo Streaming Benchmark: %sFilter_GPU -> Map_GPU(join) -> %sKey_FFAT_GPU 10 s tumbling count per campaign"
+                                 % ("split_gpu(ad type) x2 -> " if args.ysb_split_merge else "", "merge -> " if args.ysb_split_merge else ""),
                           "win_seq": "Key_Farm_GPU non-incremental sliding-window sum (%s)" % ("wave_reduce" if args.wave_reduce else "opaque functor")}
                 .get(args.pipeline, args.pipeline),
                 "global_batch": tuples_per_step_gpu * world,

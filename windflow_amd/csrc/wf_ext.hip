@@ -815,10 +815,10 @@ public:
             scfg.pool_slabs = inflight;
             split_gpu(*mp, ysb::AdTypeSplit(), 2, scfg);
             MultiPipe& b0 = mp->select(0);
-            b0.add(*filter_[0]);
+            b0.chain(*filter_[0]);
             b0.chain(*join_[0]);
             MultiPipe& b1 = mp->select(1);
-            b1.add(*filter_[1]);
+            b1.chain(*filter_[1]);
             b1.chain(*join_[1]);
             mp = &b0.merge(b1);
         } else {

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <functional>
 #include <iostream>
+#include <atomic>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <type_traits>
@@ -64,8 +66,16 @@ enum role_t { SEQ, PLQ, WLQ, MAP, REDUCE };
 // configuration error: the reference prints and exit()s; we do
 // the same by default but go through one function so tests can intercept it.
 [[noreturn]] inline void fatal_error(const std::string& msg) {
+    // Several runtime threads can hit the same condition at once (every replica of an operator whose key table is full):
+    // the first one reports and ends the process WITHOUT running static destructors under the feet of the others
+    // (exit() from two threads is undefined behaviour and used to end in a segmentation fault); the others wait for it.
+    static std::atomic<bool> once{false};
+    if (once.exchange(true)) {
+        for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+    }
     std::cerr << WF_RED << "WindFlow Error: " << msg << WF_DEFAULT_COLOR << std::endl;
-    std::exit(EXIT_FAILURE);
+    std::fflush(nullptr);
+    std::_Exit(EXIT_FAILURE);
 }
 
 // Position of a window replica inside (possibly nested) window-parallel

@@ -416,8 +416,10 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         }
         const size_t n = s.replicas.size();
         const bool last_stage = (si + 1 == stages.size());
-        const bool can_chain = try_chain && stages.size() == 1 && s.routing == FORWARD && !fresh_from_split_ && !force_shuffle_ &&
-                               prev.size() == n;
+        // (the first operator of a split branch cannot be chained on tuple edges - reference: MultiPipe::chain after split - but on
+        // batch edges a branch is just one more output port of the device splitter: its work can stay in the splitter's thread)
+        const bool can_chain = try_chain && stages.size() == 1 && s.routing == FORWARD && (!fresh_from_split_ || tail_kind_ != EDGE_TUPLE) &&
+                               !force_shuffle_ && prev.size() == n;
         const bool direct = !s.internal && s.routing == FORWARD && !fresh_from_split_ && !force_shuffle_ && prev.size() == n;
         if (can_chain) {
             // same thread as the producer (reference: chain_operator, pipegraph.hpp:1273-1318)
