@@ -481,7 +481,19 @@ public:
             case EDGE_DEVICE_BATCH: {
                 gpu::Batch* d = static_cast<gpu::Batch*>(msg);
                 if (d->device != cfg_.gpu_id) d = pull_from_peer(d);
-                d->ready.edge_wait(*stream_);
+                // Fused onto its only producer, the replica continues on the PRODUCER'S stream: the two never run
+                // concurrently anyway, stream order replaces the event wait between them, and the chain of a lane
+                // occupies one stream instead of one per stage (streams share a few hardware queues: fewer of them, and
+                // no barrier packets between them, is what keeps the queues moving - profiles/r1_sync_policy).
+                if (inherit_stream_ && this->fed_in_thread_by_one() && d->device == cfg_.gpu_id && d->ready.recorded_on() != nullptr &&
+                    d->ready.recorded_on() != cur_stream_) {
+                    // what this replica enqueued so far (table set-up in gpu_init, earlier batches) stays ahead of what follows
+                    if (!handoff_) handoff_.reset(new gpu::Event());
+                    handoff_->record(stream());
+                    cur_stream_ = d->ready.recorded_on();
+                    handoff_->wait_on(cur_stream_);
+                }
+                d->ready.edge_wait(stream());
                 reaper_.tick(stream());
                 gpu::TraceRange tr("wf:enqueue_kernels");
                 process_device(d);
@@ -513,6 +525,7 @@ public:
     }
 
     void svc_end() override {
+        if (cur_stream_) (void)hipStreamSynchronize(cur_stream_);
         if (stream_) stream_->sync();
         Replica_Base::svc_end();
     }
@@ -528,7 +541,7 @@ protected:
         s.bytes_copied_hd = bytes_hd_;
         s.bytes_copied_dh = bytes_dh_;
     }
-    hipStream_t stream() const { return stream_->get(); }
+    hipStream_t stream() const { return cur_stream_ ? cur_stream_ : stream_->get(); }
     // hand an input slab back after the work enqueued so far (whichever GPU's context owns the slab)
     void release_input(gpu::Batch* b) { gpu::release_after(b, stream(), cfg_.gpu_id, foreign_); }
     // record completion on the batch and pass it downstream
@@ -620,6 +633,9 @@ private:
     }
 
     hipStream_t upload_stream_ = nullptr;
+    hipStream_t cur_stream_ = nullptr;  // the producer's stream, once inherited (see svc)
+    bool inherit_stream_ = gpu::inherit_streams();
+    std::unique_ptr<gpu::Event> handoff_;
     gpu::ForeignReleaser foreign_;
     std::deque<gpu::Batch*> uploading_;
     gpu::StreamReaper reaper_;

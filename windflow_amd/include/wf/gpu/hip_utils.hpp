@@ -231,6 +231,14 @@ inline bool pool_wait_on_host() {
     }();
     return h;
 }
+// WF_INHERIT_STREAMS=0: a GPU replica fused onto its producer keeps a stream of its own instead of continuing on the producer's
+inline bool inherit_streams() {
+    static const bool h = [] {
+        const char* e = std::getenv("WF_INHERIT_STREAMS");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return h;
+}
 // WF_EDGE_WAIT=host|device: how a GPU operator waits for the producer of a DEVICE batch that arrives from another
 // operator's stream
 inline bool edge_wait_on_host() {
@@ -296,10 +304,14 @@ public:
     void record(hipStream_t s) {
         WF_HIP_CHECK(hipEventRecord(e_, s));
         recorded_ = true;
+        stream_ = s;
     }
-    // make stream s wait for the event (no-op if never recorded or already complete: a wait parks a barrier
-    // packet in the stream's hardware queue, which other streams share)
+    // the stream the event was last recorded on (nullptr: never recorded)
+    hipStream_t recorded_on() const { return recorded_ ? stream_ : nullptr; }
+    // make stream s wait for the event (no-op if never recorded, recorded on s itself - stream order already holds - or
+    // already complete: a wait parks a barrier packet in the stream's hardware queue, which other streams share)
     void wait_on(hipStream_t s) const {
+        if (recorded_ && stream_ == s) return;
         if (!done()) WF_HIP_CHECK(hipStreamWaitEvent(s, e_, 0));
     }
     void host_sync() const {
@@ -318,9 +330,11 @@ public:
 private:
     hipEvent_t e_ = nullptr;
     bool recorded_ = false;
+    hipStream_t stream_ = nullptr;
 };
 
 inline void Event::edge_wait(hipStream_t s) const {
+    if (recorded_ && stream_ == s) return;
     if (edge_wait_on_host())
         host_sync();
     else

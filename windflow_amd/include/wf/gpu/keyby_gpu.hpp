@@ -153,6 +153,41 @@ public:
                            sorted.keys, sorted.vals, offsets_.data(), tab, (uint32_t)n_dest_);
         kernels += 3 + sorter_.kernels_per_sort(bits_);
     }
+    // A handful of destinations (the device split of a PipeGraph): one stable compaction pass per destination - the fused
+    // predicate + compaction kernel of Filter_GPU with the predicate "fn(tuple) % n_dest == d" - instead of the sort: n_dest
+    // launches that stream the batch, no index arrays.
+    template <typename DestFn>
+    struct DestIs {
+        DestFn fn;
+        uint32_t n_dest, d;
+        __host__ __device__ bool operator()(const T& t, uint32_t) const { return (uint32_t)((uint64_t)fn(t) % n_dest) == d; }
+    };
+    template <typename DestFn>
+    void partition_few(Batch* in, hipStream_t s, std::vector<Batch*>& outs, uint64_t& kernels, DestFn fn) {
+        const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
+        if (pool_ && upper > pool_->capacity()) failwith("BatchPartitioner: a batch larger than the first one received");
+        if (!pool_) {
+            pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(T), in->capacity, n_dest_ * pool_slabs_));
+            ws_words_ = filter_workspace_words(in->capacity);
+            ws_.resize(ws_words_ * n_dest_);
+        }
+        outs.clear();
+        const size_t words = filter_workspace_words(std::max<size_t>(upper, 1));
+        WF_HIP_CHECK(hipMemsetAsync(ws_.data(), 0, ws_words_ * n_dest_ * sizeof(unsigned long long), s));
+        const unsigned cgrid = (unsigned)std::max<size_t>(1, (upper + FILTER_TILE - 1) / FILTER_TILE);
+        (void)words;
+        for (size_t d = 0; d < n_dest_; d++) {
+            Batch* o = pool_->acquire(s);
+            o->host_hdr = in->host_hdr;
+            o->count_on_host = false;
+            hipLaunchKernelGGL((filter_compact_kernel<T, DestIs<DestFn>>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                               o->header(), o->template data<T>(), o->count_mirror, ws_.data() + d * ws_words_,
+                               DestIs<DestFn>{fn, (uint32_t)n_dest_, (uint32_t)d});
+            outs.push_back(o);
+        }
+        kernels += n_dest_;
+    }
+    static constexpr size_t FEW_DESTINATIONS = 4;
     // Packed form for the cross-GPU exchange: destinations are (rank, lane) pairs, the output is one slab ordered by
     // destination; mirror_for(slab) names the pinned array (n_ranks * n_lanes + 1 words) that receives the segment offsets
     // of that slab.
@@ -205,6 +240,8 @@ private:
     int bits_ = 1;
     std::unique_ptr<BatchPool> pool_;
     DeviceBuffer<uint32_t> dest_, idx_, offsets_;
+    DeviceBuffer<unsigned long long> ws_;
+    size_t ws_words_ = 0;
     RadixSorter sorter_;
 };
 
@@ -259,6 +296,8 @@ public:
         std::vector<gpu::Batch*> outs;
         if constexpr (std::is_void_v<DestFn>)
             part_.partition(d, s, outs, kernels_);
+        else if (n_dest_ <= gpu::BatchPartitioner<T>::FEW_DESTINATIONS)
+            part_.partition_few(d, s, outs, kernels_, fn_);
         else
             part_.partition_with(d, s, outs, kernels_, fn_);
         WF_HIP_CHECK(hipGetLastError());

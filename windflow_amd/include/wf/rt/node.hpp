@@ -102,6 +102,9 @@ public:
     virtual void svc_end() {}
     // nodes with asynchronous work in flight (device copies...) can ask to be polled
     // whenever their thread has no input to process
+    // true when the node is fed by ONE producer of its own thread (fused onto it): the two then run strictly one after the
+    // other, which GPU nodes use to share the producer's stream
+    bool fed_in_thread_by_one() const { return in_.empty() && n_in_ == 1; }
     virtual bool wants_idle() const { return false; }
     virtual void on_idle() {}
 

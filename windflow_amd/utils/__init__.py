@@ -25,6 +25,7 @@ RUNTIME_ENV = {
     "WF_D2H_STREAMS": "own: every DeviceToHost adapter copies on its own stream; shared: on the producer's",
     "WF_POOL_WAIT": "host | device: where a re-acquired slab's last use is waited for (host)",
     "WF_EDGE_WAIT": "host | device: where a consumer waits for the event of a batch produced by another stream (device)",
+    "WF_INHERIT_STREAMS": "0: a GPU replica fused onto its producer keeps its own stream instead of continuing on the producer's (1)",
     "WF_EVENT_BLOCKING": "1: host waits on events sleep instead of spinning",
     "WF_STREAM_REAP": "how often finished stream work is reaped",
     "WF_HIP_GRAPHS": "1: Key_FFAT_GPU replays its per-batch launch sequence from a hipGraph (0: measured not to be faster)",
