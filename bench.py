@@ -209,23 +209,81 @@ def run_dp_probe(args, world, limit_s=90):
     return {"status": "ok (this rank printed no result)"}
 
 
-def run_preflight(kind, world, local_rank):
-    """Child-process body of the transport self-test: a tiny keyby pipeline over `kind`; exit status 0 = it moved tuples
-    between the ranks and lost none."""
+def make_pipeline(args, ext, local_rank):
+    """The native pipeline the arguments describe (its constructor starts the graph's threads)."""
+    keys_per_source = max(1, args.keys // args.sources)
+    if args.pipeline == "map_filter":
+        return ext.MapFilterPipeline(local_rank, args.sources, args.batch, keys_per_source, args.inflight)
+    elif args.pipeline == "win_agg":
+        if args.count_based:
+            win, slide = args.win, args.slide
+        else:
+            # one tuple per microsecond per source, keys round-robin: a key ticks every keys_per_source us
+            win, slide = args.win * keys_per_source, args.slide * keys_per_source
+        transport = None
+        if args.parallelism == "keyby":
+            from windflow_amd import parallel as wfpar
+
+            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
+        # n_keys: per source when the sources own disjoint key sets, the whole key space (of this GPU) when they share it
+        return ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source * args.sources if args.shared_keys else keys_per_source,
+                                  win, slide, not args.count_based, 0, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
+                                  args.zipf_alpha, args.shared_keys)
+    elif args.pipeline == "win_seq":
+        # BASELINE.json config 3: count-based sliding windows, non-incremental user function.  A single key cannot be split
+        # over sources that own disjoint key sets: every source then emits it and one replica aggregates
+        shared = args.shared_keys or args.keys < args.sources
+        replicas = args.replicas or (min(args.sources, max(1, args.keys)) if shared else 0)
+        # n_keys: per source when the sources own disjoint key sets, the whole key space when they share it
+        return ext.WinSeqPipeline(local_rank, args.sources, args.batch, max(1, args.keys) if shared else max(1, args.keys // args.sources),
+                                  args.win, args.slide, False, args.inflight, replicas, args.wave_reduce, KEY_DISTS[args.key_dist],
+                                  args.zipf_alpha, shared)
+    elif args.pipeline == "ysb":
+        transport = None
+        if args.parallelism == "keyby":
+            from windflow_amd import parallel as wfpar
+
+            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
+        return ext.YsbPipeline(local_rank, args.sources, args.batch, args.ysb_period_us, args.ysb_delay_us, args.inflight,
+                               args.agg_replicas or 1, transport, args.ysb_split_merge)
+    else:
+        raise SystemExit("unknown pipeline %r" % args.pipeline)
+
+
+def run_preflight(kind, world, local_rank, args):
+    """Child-process body of the transport self-test: a tiny keyby pipeline over `kind`, then two steps of the pipeline that
+    is going to be timed, at its real size (slab sizes, round sizes and the number of lanes are what a fabric or a memory
+    limit would object to); exit status 0 = both moved their tuples between the ranks and lost none."""
     from windflow_amd import load_ext, parallel as wfpar
 
     env = wfpar.init_distributed()
+    ext = load_ext()
+
+    def agreed(ok):
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
     transport = (wfpar.ipc_transport if kind == "ipc" else wfpar.rccl_transport)(env, local_rank)
-    pipe = load_ext().WinAggPipeline(local_rank, 2, 4096, 64, 8, 2, False, 0, 4, transport, 2)
+    pipe = ext.WinAggPipeline(local_rank, 2, 4096, 64, 8, 2, False, 0, 4, transport, 2)
     pipe.step(40_000)
     pipe.step(40_000)
     pipe.close()
     st = pipe.stats()
-    ok = st["overflow"] == 0 and st["table_full"] == 0 and st["exchange_tuples_sent"] == 160_000 and st["sink_tuples"] > 0
-    t = torch.tensor([1 if ok else 0])
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    ok = agreed(st["overflow"] == 0 and st["table_full"] == 0 and st["exchange_tuples_sent"] == 160_000 and st["sink_tuples"] > 0)
+    del pipe, transport
+    if ok and args.pipeline in ("win_agg", "ysb") and not os.environ.get("WF_BENCH_SHORT_PREFLIGHT"):
+        args.parallelism, args.transport = "keyby", kind
+        per_source = max(1, args.tuples_per_step // args.sources)
+        pipe = make_pipeline(args, ext, local_rank)
+        pipe.step(per_source)
+        pipe.step(per_source)
+        pipe.close()
+        st = pipe.stats()
+        ok = agreed(st.get("overflow", 0) == 0 and st.get("table_full", 0) == 0 and st["sink_tuples"] > 0
+                    and st.get("exchange_tuples_sent", 1) > 0)
     wfpar.shutdown()
-    return 0 if int(t.item()) == 1 else 1
+    return 0 if ok else 1
 
 
 def preflight_ok(kind, world, port_offset, limit_s=150):
@@ -235,7 +293,7 @@ def preflight_ok(kind, world, port_offset, limit_s=150):
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--preflight", kind, "--gpus", str(world)]
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--preflight", kind, "--gpus", str(world)]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
         ok, why = r.returncode == 0, (r.stderr or "")[-200:]
@@ -286,7 +344,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     if args.preflight:
-        raise SystemExit(run_preflight(args.preflight, world, local_rank))
+        raise SystemExit(run_preflight(args.preflight, world, local_rank, args))
     fallback_note = None
     if args.parallelism == "keyby" and args.transport == "auto":
         if world == 1:
@@ -319,42 +377,7 @@ def main():
     per_source = max(1, args.tuples_per_step // args.sources)
     tuples_per_step_gpu = per_source * args.sources
     keys_per_source = max(1, args.keys // args.sources)
-    if args.pipeline == "map_filter":
-        pipe = ext.MapFilterPipeline(local_rank, args.sources, args.batch, keys_per_source, args.inflight)
-    elif args.pipeline == "win_agg":
-        if args.count_based:
-            win, slide = args.win, args.slide
-        else:
-            # one tuple per microsecond per source, keys round-robin: a key ticks every keys_per_source us
-            win, slide = args.win * keys_per_source, args.slide * keys_per_source
-        transport = None
-        if args.parallelism == "keyby":
-            from windflow_amd import parallel as wfpar
-
-            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
-        # n_keys: per source when the sources own disjoint key sets, the whole key space (of this GPU) when they share it
-        pipe = ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source * args.sources if args.shared_keys else keys_per_source,
-                                  win, slide, not args.count_based, 0, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
-                                  args.zipf_alpha, args.shared_keys)
-    elif args.pipeline == "win_seq":
-        # BASELINE.json config 3: count-based sliding windows, non-incremental user function.  A single key cannot be split
-        # over sources that own disjoint key sets: every source then emits it and one replica aggregates
-        shared = args.shared_keys or args.keys < args.sources
-        replicas = args.replicas or (min(args.sources, max(1, args.keys)) if shared else 0)
-        # n_keys: per source when the sources own disjoint key sets, the whole key space when they share it
-        pipe = ext.WinSeqPipeline(local_rank, args.sources, args.batch, max(1, args.keys) if shared else max(1, args.keys // args.sources),
-                                  args.win, args.slide, False, args.inflight, replicas, args.wave_reduce, KEY_DISTS[args.key_dist],
-                                  args.zipf_alpha, shared)
-    elif args.pipeline == "ysb":
-        transport = None
-        if args.parallelism == "keyby":
-            from windflow_amd import parallel as wfpar
-
-            transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
-        pipe = ext.YsbPipeline(local_rank, args.sources, args.batch, args.ysb_period_us, args.ysb_delay_us, args.inflight,
-                               args.agg_replicas or 1, transport, args.ysb_split_merge)
-    else:
-        raise SystemExit("unknown pipeline %r" % args.pipeline)
+    pipe = make_pipeline(args, ext, local_rank)
 
     def barrier():
         if world > 1:
