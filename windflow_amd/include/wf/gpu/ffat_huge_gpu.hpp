@@ -16,10 +16,14 @@
 //                                fills the panes no tuple fell into (time-based windows), appends the panes to the key's
 //                                tree in HBM, advances the key's state and reserves room in the output batch for the
 //                                windows the run fires
-//   5. ffat_huge_windows_kernel  one thread per fired window over the leaves (old panes of the key in front, new ones behind)
+//   5. ffat_huge_hgw_kernel      windows of more than FFAT_HUGE_DIRECT_WIN panes only: the leaves are cut in blocks of W = panes per
+//                                window, and one wave per block computes the block's inclusive prefix folds, another its suffix
+//                                folds (van Herk / Gil-Werman): a window that starts at leaf s is suffix[s] (+) prefix[s + W - 1],
+//                                one combine whatever W is, and the order of the panes is kept (the combine need not commute)
+//   6. ffat_huge_windows_kernel  one thread per fired window: that one combine, or for short windows a fold over the W leaves
+//                                (old panes of the key in front, new ones behind)
 // Used for count-based windows and for time-based windows without triggering delay whose run is in timestamp order and not
-// sparse in time; everything else (and windows of more than FFAT_HUGE_MAX_WIN panes) goes to the wave-per-run kernel, which
-// implements the full rules.  The engine switches these five launches on when a batch shows a huge run and off again after
+// sparse in time; everything else goes to the wave-per-run kernel, which implements the full rules.  The engine switches these five launches on when a batch shows a huge run and off again after
 // a while without one (key_ffat_gpu.hpp), so streams without hot keys do not pay for them.
 //
 // Reference: the reference engine (wf/win_seqffat_gpu.hpp:369-396 + wf/flatfat_gpu.hpp:251-434) handles ONE key per replica
@@ -33,7 +37,7 @@ namespace wf {
 namespace gpu {
 
 constexpr uint32_t FFAT_HUGE_RUN = 2048;    // tuples of one key in one batch from which the run is spread over the chip
-constexpr uint32_t FFAT_HUGE_MAX_WIN = 64;  // panes per window up to which a fired window is folded directly from the leaves
+constexpr uint32_t FFAT_HUGE_DIRECT_WIN = 12;  // panes per window up to which a fired window is folded directly from the leaves
 
 template <typename R>
 struct FFATPartial {
@@ -339,7 +343,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         // the panes a window fired by this run can still need, in front of the new ones
         for (uint32_t j = (uint32_t)lane; j + 1 < W; j += WAVE) {
             const uint64_t back = (uint64_t)(W - 1 - j);  // pane P0 - back
-            if (hr.P0 >= back) lv[-(int64_t)back] = gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))];
+            // (the key's first windows: the panes before pane 0 do not exist; no window reaches them, the block scans may)
+            lv[-(int64_t)back] = hr.P0 >= back ? gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))] : R{};
         }
         // what was open before the run is the head of pane 0 (the carry is kept identical in every lane)
         bool c_has = false;
@@ -452,10 +457,67 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// Block-wise prefix and suffix folds of the leaves of every huge run (see 5. above).  Array coordinates: a = 0 is the oldest
+// of the W - 1 old panes, the run's own panes start at a = W - 1, `(W - 1) + m` entries are complete.  Work item 2 * b is
+// the prefix scan of block b, 2 * b + 1 its suffix scan; a wave scans 64 entries per step and carries the fold along.
 template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_huge_windows_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const R* leaves, R* out, FFATCounters* ctr,
-                             const unsigned long long* table, C comb) {
+    ffat_huge_hgw_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const R* leaves, R* pre, R* suf, C comb) {
+    const uint32_t nr = ctl->n_runs;
+    const uint32_t W = g.win_panes;
+    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
+    const uint32_t gw = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id();
+    const int lane = lane_id();
+    for (uint32_t r = 0; r < nr; r++) {
+        const FFATHugeRun& hr = runs[r];
+        if (hr.fallback || hr.nf == 0) continue;
+        const uint32_t n_valid = (W - 1) + hr.m;
+        const uint32_t items = 2 * ((n_valid + W - 1) / W);
+        const R* arr = leaves + (size_t)hr.leaf_base;
+        for (uint32_t it = gw; it < items; it += waves_total) {
+            const uint32_t lo = (it >> 1) * W, hi = lo + W < n_valid ? lo + W : n_valid;
+            const bool backwards = (it & 1u) != 0;
+            R* dst = (backwards ? suf : pre) + (size_t)hr.leaf_base;
+            bool c_has = false;
+            R c_val{};
+            for (uint32_t done = 0; lo + done < hi; done += WAVE) {
+                const uint32_t left = hi - lo - done, cnt = left < (uint32_t)WAVE ? left : (uint32_t)WAVE;
+                const bool ok = (uint32_t)lane < cnt;
+                // lane order = fold order: ascending entries for the prefix, descending ones for the suffix
+                const uint32_t a = backwards ? hi - 1 - done - (uint32_t)lane : lo + done + (uint32_t)lane;
+                R val{};
+                if (ok) val = arr[a];
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const R other = wave_shfl_up(val, d);
+                    if (ok && lane >= d) {
+                        R tmp;
+                        if (backwards)
+                            fat_combine(comb, val, other, tmp);  // the lower lanes hold the LATER panes
+                        else
+                            fat_combine(comb, other, val, tmp);
+                        val = tmp;
+                    }
+                }
+                if (c_has && ok) {
+                    R tmp;
+                    if (backwards)
+                        fat_combine(comb, val, c_val, tmp);
+                    else
+                        fat_combine(comb, c_val, val, tmp);
+                    val = tmp;
+                }
+                if (ok) dst[a] = val;
+                c_val = wave_bcast(val, (int)cnt - 1);
+                c_has = true;
+            }
+        }
+    }
+}
+
+template <typename R, typename C>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_huge_windows_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const R* leaves, const R* pre, const R* suf, R* out,
+                             FFATCounters* ctr, const unsigned long long* table, C comb) {
     const uint32_t nr = ctl->n_runs;
     const uint32_t W = g.win_panes;
     for (uint32_t r = 0; r < nr; r++) {
@@ -467,11 +529,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < hr.nf; w += gridDim.x * blockDim.x) {
             const uint64_t k = hr.first_lwid + w;
             const int64_t first = (int64_t)(k * g.slide_panes) - (int64_t)hr.P0;  // >= -(W - 1)
-            R res = lv[first];
-            for (uint32_t p = 1; p < W; p++) {
-                R tmp;
-                fat_combine(comb, res, lv[first + (int64_t)p], tmp);
-                res = tmp;
+            R res;
+            if (pre != nullptr) {
+                const size_t a = (size_t)hr.leaf_base + (size_t)(first + (int64_t)(W - 1));  // array coordinate of the first pane
+                res = suf[a];
+                if ((first + (int64_t)(W - 1)) % (int64_t)W != 0) {  // not a whole block: the rest is a prefix of the next one
+                    R tmp;
+                    fat_combine(comb, res, pre[a + W - 1], tmp);
+                    res = tmp;
+                }
+            } else {
+                res = lv[first];
+                for (uint32_t p = 1; p < W; p++) {
+                    R tmp;
+                    fat_combine(comb, res, lv[first + (int64_t)p], tmp);
+                    res = tmp;
+                }
             }
             res.setControlFields(key, k, cf_ts(res));
             const uint32_t pos = hr.out_base + w;

@@ -769,8 +769,8 @@ public:
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
         n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
         WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
-        // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones without a triggering delay, of few enough panes
-        huge_ok_ = (!g_.is_tb || delay == 0) && g_.win_panes <= FFAT_HUGE_MAX_WIN && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
+        // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones without a triggering delay
+        huge_ok_ = (!g_.is_tb || delay == 0) && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
         if (huge_ok_) {
             huge_max_runs_ = (uint32_t)(batch_cap_ / FFAT_HUGE_RUN + 1);
             huge_leaves_cap_ = (uint32_t)(batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70));
@@ -780,6 +780,10 @@ public:
             huge_parts_.resize(2 * (batch_cap_ / WAVE + huge_max_runs_));
             huge_parts2_.resize(2 * (2 * (batch_cap_ / WAVE + huge_max_runs_) / WAVE + huge_max_runs_));
             huge_leaves_.resize(huge_leaves_cap_);
+            if (g_.win_panes > FFAT_HUGE_DIRECT_WIN) {
+                huge_pre_.resize(huge_leaves_cap_);
+                huge_suf_.resize(huge_leaves_cap_);
+            }
             WF_HIP_CHECK(hipHostMalloc((void**)&huge_seen_, 64, hipHostMallocDefault));
             *huge_seen_ = 0;
         }
@@ -881,8 +885,17 @@ private:
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
                                    acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
                                    out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
+                const bool hgw = g_.win_panes > FFAT_HUGE_DIRECT_WIN;
+                if (hgw) {
+                    // two work items per block of win_panes leaves, a wave each
+                    const size_t items = 2 * ((size_t)huge_leaves_cap_ / g_.win_panes + huge_max_runs_);
+                    const unsigned hgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, items / (BLOCK_THREADS / WAVE) + 1));
+                    hipLaunchKernelGGL((ffat_huge_hgw_kernel<R, C>), dim3(hgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
+                                       huge_leaves_.data(), huge_pre_.data(), huge_suf_.data(), comb_);
+                }
                 hipLaunchKernelGGL((ffat_huge_windows_kernel<R, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
-                                   huge_leaves_.data(), out->template data<R>(), counters_.data(), table_.data(), comb_);
+                                   huge_leaves_.data(), hgw ? huge_pre_.data() : (const R*)nullptr, hgw ? huge_suf_.data() : (const R*)nullptr,
+                                   out->template data<R>(), counters_.data(), table_.data(), comb_);
             }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
@@ -951,7 +964,7 @@ private:
     DeviceBuffer<FFATHugeRun> huge_runs_;
     DeviceBuffer<FFATHugeCtl> huge_ctl_;
     DeviceBuffer<FFATPartial<R>> huge_parts_, huge_parts2_;
-    DeviceBuffer<R> huge_leaves_;
+    DeviceBuffer<R> huge_leaves_, huge_pre_, huge_suf_;
     // hipGraph cache
     struct GraphKey {
         const void* in;
