@@ -326,7 +326,8 @@ template <typename R>
 struct FFATLongLayout {
     uint32_t tree_nodes;  // 0: the tree stays in global memory
     uint32_t acc_slots;   // 0: the ring of open quanta stays in global memory
-    uint32_t bulk;        // 1: tree_nodes = 2 * FFAT_WORK_LEAVES, a working tree private to the run (bulk path)
+    uint32_t bulk;        // 1: tree_nodes = 2 * FFAT_WORK_LEAVES, a working tree private to the run (bulk path);
+                          // 2: bulk path on the key's own tree in global memory (windows of more than 64 panes)
     __host__ __device__ static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
     __host__ __device__ size_t segs_off() const { return 0; }
     __host__ __device__ size_t res_off() const { return align16(WAVE * sizeof(FFATSegment<R>)); }
@@ -344,6 +345,8 @@ struct FFATLongLayout {
         if (with_tree.wave_bytes() <= budget) l = with_tree;
         FFATLongLayout with_bulk{2 * FFAT_WORK_LEAVES, acc, 1};
         if (g.win_panes + WAVE <= FFAT_WORK_LEAVES && with_bulk.wave_bytes() <= budget) l = with_bulk;
+        FFATLongLayout global_bulk{0, acc, 2};
+        if (l.bulk == 0 && g.win_panes + WAVE <= g.tree_cap && global_bulk.wave_bytes() <= budget) l = global_bulk;
         return l;
     }
 };
@@ -381,6 +384,36 @@ __device__ __forceinline__ void fat_rebuild_wave(R* tree, uint32_t cap, const C&
     }
 }
 
+// recompute the ancestors of `count` consecutive leaves that start at circular position `first`: one level per step, a lane
+// per dirty node (count / 2 + 1 nodes on the first level, half of that on the next, ... then the path to the root)
+template <typename R, typename C>
+__device__ __forceinline__ void fat_rebuild_range_wave(R* tree, uint32_t cap, uint32_t first, uint32_t count, const C& comb) {
+    if (count == 0) return;
+    if (count >= cap) {
+        fat_rebuild_wave(tree, cap, comb);
+        return;
+    }
+    first &= cap - 1;
+    // the circular range is one or two linear ranges of leaves; [lo, hi] inclusive, n2 == 0: no second range
+    uint32_t lo1 = first, hi1 = (first + count <= cap ? first + count : cap) - 1;
+    uint32_t lo2 = 0, hi2 = 0, n2 = first + count > cap ? 1u : 0u;
+    if (n2) hi2 = first + count - cap - 1;
+    for (uint32_t width = cap >> 1; width >= 1; width >>= 1) {
+        lo1 >>= 1;
+        hi1 >>= 1;
+        lo2 >>= 1;
+        hi2 >>= 1;
+        const uint32_t c1 = hi1 - lo1 + 1, c2 = n2 ? hi2 - lo2 + 1 : 0;  // (nodes the two ranges share are computed twice: same value)
+        for (uint32_t j = (uint32_t)lane_id(); j < c1 + c2; j += WAVE) {
+            const uint32_t node = width + (j < c1 ? lo1 + j : lo2 + (j - c1));
+            R tmp;
+            fat_combine(comb, tree[2 * node], tree[2 * node + 1], tmp);
+            tree[node] = tmp;
+        }
+        wave_sync_lds();
+    }
+}
+
 // Long runs: one wave64 per run, exploiting the associativity of the combine.
 //  * all chunks: the 64 lanes gather and LIFT the next 64 tuples of the run together; lanes whose tuples
 //    fall in the same pane (CB) / quantum (TB) form a segment and an order-preserving segmented wave scan
@@ -389,9 +422,12 @@ __device__ __forceinline__ void fat_rebuild_wave(R* tree, uint32_t cap, const C&
 //    the chunk are written side by side as leaves of a 128-leaf working tree private to the run (LDS),
 //    the tree is rebuilt a level per step, and every window fired by the chunk is evaluated by a lane of
 //    its own - nothing is sequential per tuple, per pane or per window;
+//  * bulk path on the key's own tree (GBULK; windows of more than 64 panes): the same, but the completed panes go straight
+//    to the leaves of the key's tree in global memory, only the ancestors of the new leaves are recomputed (a lane per
+//    dirty node and level) and every fired window is a lane's O(log) query of that tree;
 //  * otherwise lane 0 folds the segments one by one (same rules as ffat_fold), on the staged tree.
 // The windows fired by a chunk leave with one atomic.
-template <typename T, typename R, typename L, typename C>
+template <bool GBULK, typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
                             R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
@@ -407,7 +443,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     uint8_t* lused = reinterpret_cast<uint8_t*>(my + lay.used_off());
     WaveEmit<R> emit{reinterpret_cast<R*>(my + lay.res_off()), 0u, out, out_count, g.out_cap, ctr};
     const bool bulk = lay.bulk != 0;
-    constexpr uint32_t CW = FFAT_WORK_LEAVES;
+    // leaves of the tree the bulk path works on
+    const uint32_t CW = GBULK ? g.tree_cap : FFAT_WORK_LEAVES;
     // geometry seen by the sequential rules when they work on the private tree
     FFATGeometry gw = g;
     if (bulk) gw.tree_cap = CW;
@@ -417,7 +454,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t slot = sslot[head];
         FFATKeyState<R> st = states[slot];  // bulk: identical in every lane; otherwise lane 0's copy is the live one
         R* gtree = trees + (size_t)slot * 2 * g.tree_cap;
-        if (bulk) {
+        // the tree of the bulk path (one instantiation per address space: ds_* or global_* instructions, not flat ones)
+        R* wtree;
+        if constexpr (GBULK)
+            wtree = gtree;
+        else
+            wtree = ltree;
+        if (bulk && !GBULK) {
             // import the panes a future window can still need
             const uint64_t lo = st.panes > g.win_panes ? st.panes - g.win_panes : 0;
             for (uint64_t idx = lo + lane; idx < st.panes; idx += WAVE)
@@ -444,7 +487,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         decltype(cf_key(st.partial)) run_key{};
         auto fire_pending = [&]() {
             if (pend == 0) return;
-            fat_rebuild_wave(ltree, CW, comb);
+            if constexpr (GBULK)
+                fat_rebuild_range_wave(wtree, CW, (uint32_t)((st.panes - pend) & (CW - 1)), pend, comb);
+            else
+                fat_rebuild_wave(wtree, CW, comb);
             // windows k in [next_lwid, k_end), window k = panes [k*slide, k*slide + win)
             const uint64_t Pn = st.panes;
             const uint64_t k_end = Pn >= g.win_panes ? (Pn - g.win_panes) / g.slide_panes + 1 : 0;
@@ -458,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             if ((uint32_t)lane < nf) {
                 const uint64_t k = st.next_lwid + (uint64_t)lane;
                 R res;
-                fat_query_circular(ltree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
+                fat_query_circular(wtree, CW, (uint32_t)((k * g.slide_panes) & (CW - 1)), g.win_panes, res, comb);
                 res.setControlFields(run_key, k, cf_ts(res));
                 emit.buf[emit.n + (uint32_t)lane] = res;
             }
@@ -534,7 +580,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     if (pend + m > (uint32_t)WAVE) fire_pending();
                     if (tail) {
                         if (seg == 0 && pc0 > 0) fat_combine(comb, st.partial, val, open_val);
-                        if ((uint32_t)seg < m) ltree[CW + (uint32_t)((P + (uint64_t)seg) & (CW - 1))] = open_val;
+                        if ((uint32_t)seg < m) wtree[CW + (uint32_t)((P + (uint64_t)seg) & (CW - 1))] = open_val;
                     }
                     const uint32_t rem = (uint32_t)(total % g.pane_len);
                     const R last_val = wave_bcast(open_val, (int)cnt - 1);  // the last segment: the new open pane when rem > 0
@@ -551,7 +597,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                         R e{};
                         if (lane == 0 && open_used) e = lacc[(uint32_t)(Lq & amask)];  // ... except the one that was already open
                         e.setControlFields(key, Lq + (uint64_t)lane, (Lq + (uint64_t)lane + 1) * g.pane_len - 1);
-                        ltree[CW + (uint32_t)((P + (uint64_t)lane) & (CW - 1))] = e;
+                        wtree[CW + (uint32_t)((P + (uint64_t)lane) & (CW - 1))] = e;
                     }
                     wave_sync_lds();
                     // ... and the segments overwrite theirs
@@ -561,7 +607,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                         if (x < m) {
                             R v = open_val;
                             v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
-                            ltree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
+                            wtree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
                         }
                     }
                     const R last_val = wave_bcast(open_val, (int)cnt - 1);  // quantum q_last stays open
@@ -619,7 +665,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         fire_pending();
         emit.flush_wave();  // whatever the last chunks parked
         wave_sync_lds();
-        if (bulk) {
+        if (bulk && !GBULK) {
             // export the panes a future window (or the end-of-stream flush) can still need, rebuild the key's tree
             const uint64_t lo = st.panes > g.win_panes ? st.panes - g.win_panes : 0;
             for (uint64_t idx = lo + lane; idx < st.panes; idx += WAVE)
@@ -736,6 +782,8 @@ public:
         g_.delay = delay;
         uint32_t cap = 2;
         while (cap <= g_.win_panes) cap <<= 1;
+        // long windows: the long-run kernel appends up to 64 panes to the key's tree before it evaluates the windows they fire
+        if (g_.win_panes > WAVE && cap < g_.win_panes + WAVE) cap <<= 1;
         g_.tree_cap = cap;
         uint32_t acc = 2;
         const uint64_t need = (type == TB) ? delay / pane + 2 : 1;
@@ -899,10 +947,16 @@ private:
             }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
-            hipLaunchKernelGGL((ffat_update_long_kernel<T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
-                               in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
-                               out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), long_layout_,
-                               lift_, comb_);
+            if (long_layout_.bulk == 2)
+                hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
+                                   in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
+                                   g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
+                                   long_layout_, lift_, comb_);
+            else
+                hipLaunchKernelGGL((ffat_update_long_kernel<false, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
+                                   in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
+                                   g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
+                                   long_layout_, lift_, comb_);
         }
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
                            n_long_.data() + 1);
