@@ -59,6 +59,11 @@ def parse_args():
     p.add_argument("--win", type=int, default=0, help="window length, in tuples of one key (default 16; win_seq: 1024)")
     p.add_argument("--slide", type=int, default=0, help="window slide, in tuples of one key (default 4; win_seq: 128)")
     p.add_argument("--count-based", action="store_true", help="count-based instead of time-based windows")
+    p.add_argument("--delay", type=int, default=-1,
+                   help="win_agg, time-based: triggering delay, in tuples of one key (a window fires when a tuple that much later than its "
+                        "end has arrived: the lag between the sources of a key that is tolerated without dropping tuples).  Default: 0 when "
+                        "the sources own disjoint key sets (every key's tuples arrive in order), the time span of 16 batches with "
+                        "--shared-keys (the sources of a key run up to a few batches apart; late tuples are counted in config.dropped)")
     p.add_argument("--tuples-per-step", type=int, default=int(os.environ.get("WF_BENCH_TUPLES", str(256 * 1024 * 1024))),
                    help="tuples fed per GPU per step (default 256 Mi: a step lasts ~0.2 s, so the driver's 20 steps time 4-5 s and ~40 000 batches)")
     p.add_argument("--inflight", type=int, default=0)
@@ -71,6 +76,9 @@ def parse_args():
     p.add_argument("--shared-keys", action="store_true",
                    help="every source emits every key (default: sources own disjoint key sets), which puts the device KeyBy in front of "
                         "the keyed operator")
+    p.add_argument("--deterministic", action="store_true",
+                   help="win_agg: DETERMINISTIC PipeGraph - the device KeyBy merges the lanes of its producers in timestamp order (low-watermark "
+                        "rule), so a key that several sources emit reaches its window in order and no triggering delay is needed")
     p.add_argument("--replicas", type=int, default=0, help="win_seq: Key_Farm_GPU replicas (0: one per source)")
     p.add_argument("--wave-reduce", action="store_true", help="win_seq: give the operator wave_reduce(lift, combine) instead of the opaque functor")
     p.add_argument("--no-cpu-partition", action="store_true", help="N>1: do not bind each rank to its own slice of the CPUs")
@@ -183,7 +191,7 @@ def run_dp_probe(args, world, limit_s=90):
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.dp_probe_steps), "--warmup", "1",
            "--parallelism", "dp", "--dp-probe-steps", "0", "--pipeline", args.pipeline, "--sources", str(args.sources),
-           "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide),
+           "--keys", str(args.keys), "--win", str(args.win), "--slide", str(args.slide), "--delay", str(args.delay),
            "--tuples-per-step", str(args.tuples_per_step), "--no-cpu-partition"]
     if args.count_based:
         cmd.append("--count-based")
@@ -216,10 +224,10 @@ def make_pipeline(args, ext, local_rank):
         return ext.MapFilterPipeline(local_rank, args.sources, args.batch, keys_per_source, args.inflight)
     elif args.pipeline == "win_agg":
         if args.count_based:
-            win, slide = args.win, args.slide
+            win, slide, delay = args.win, args.slide, 0
         else:
             # one tuple per microsecond per source, keys round-robin: a key ticks every keys_per_source us
-            win, slide = args.win * keys_per_source, args.slide * keys_per_source
+            win, slide, delay = args.win * keys_per_source, args.slide * keys_per_source, args.delay * keys_per_source
         transport = None
         if args.parallelism == "keyby":
             from windflow_amd import parallel as wfpar
@@ -227,8 +235,8 @@ def make_pipeline(args, ext, local_rank):
             transport = (wfpar.ipc_transport if args.transport == "ipc" else wfpar.rccl_transport)(wfpar.DistEnv(), local_rank)
         # n_keys: per source when the sources own disjoint key sets, the whole key space (of this GPU) when they share it
         return ext.WinAggPipeline(local_rank, args.sources, args.batch, keys_per_source * args.sources if args.shared_keys else keys_per_source,
-                                  win, slide, not args.count_based, 0, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
-                                  args.zipf_alpha, args.shared_keys)
+                                  win, slide, not args.count_based, delay, args.inflight, transport, args.agg_replicas, KEY_DISTS[args.key_dist],
+                                  args.zipf_alpha, args.shared_keys, args.deterministic)
     elif args.pipeline == "win_seq":
         # BASELINE.json config 3: count-based sliding windows, non-incremental user function.  A single key cannot be split
         # over sources that own disjoint key sets: every source then emits it and one replica aggregates
@@ -319,6 +327,11 @@ def main():
         args.slide = 128 if args.pipeline == "win_seq" else 4
     if args.batch <= 0:
         args.batch = 128 * 1024
+    if args.delay < 0:
+        # a source emits one tuple per microsecond; window, slide and delay are scaled by keys / sources microseconds (the
+        # pace of a key over all its sources)
+        args.delay = -(-16 * args.batch // max(1, args.keys // args.sources)) \
+            if (args.shared_keys and not args.count_based and not args.deterministic) else 0
     if args.inflight <= 0:
         args.inflight = 4
     rank = int(os.environ.get("RANK", "0"))
@@ -387,8 +400,8 @@ def main():
         pipe.step(per_source)
     pipe.reset_latency()
     elapsed = timed_steps(pipe, per_source, args.steps, barrier, args.drain_every_step)
+    pipe.close()  # (the device counters - late tuples, overflows - are collected when the operators terminate)
     stats = pipe.stats()
-    pipe.close()
     t = torch.tensor([elapsed], dtype=torch.float64)
     lat = torch.tensor([stats["latency_p99_us"]], dtype=torch.float64)
     if world > 1:
@@ -435,8 +448,10 @@ def main():
                 "sources_per_gpu": args.sources,
                 "keys_per_gpu": args.keys if args.pipeline == "win_seq" else keys_per_source * args.sources,
                 "key_distribution": args.key_dist + (" alpha=%g" % args.zipf_alpha if args.key_dist == "zipf" else ""),
+                **({"graph_mode": "DETERMINISTIC"} if args.deterministic else {}),
                 "shared_keys": bool(args.shared_keys or (args.pipeline == "win_seq" and args.keys < args.sources)),
-                "window": "%s win=%d slide=%d (tuples of a key)" % ("CB" if (args.count_based or args.pipeline == "win_seq") else "TB", args.win, args.slide),
+                "window": "%s win=%d slide=%d%s (tuples of a key)" % ("CB" if (args.count_based or args.pipeline == "win_seq") else "TB", args.win,
+                                                                       args.slide, " delay=%d" % args.delay if args.delay else ""),
                 "latency_samples": stats.get("latency_samples"),
                 "steps_streamed": "drained after every step" if args.drain_every_step else "back to back, drained once at the end of the timed region",
                 "sink_results_rank0": stats["sink_tuples"],

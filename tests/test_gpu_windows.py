@@ -240,7 +240,7 @@ def test_key_ffat_long_runs_keep_order(ext, n, n_keys, win, slide, batch, mode):
 
 def bursty_stream(n, n_keys, seed, gap_every, gap_len, disorder):
     """Per-key timestamps that advance by 1, jump by gap_len every gap_every tuples, with bounded local disorder."""
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + 7919)  # (not the seed of make_stream: the disorder would be a function of the key)
     t, vals = make_stream(n, n_keys, seed)
     ts = np.zeros(n, dtype=np.int64)
     clock = {}
@@ -272,6 +272,49 @@ def test_key_ffat_time_based_long_runs(ext, n, n_keys, win, slide, batch, gap_ev
     assert len(res) == len(got) == len(exp)
     for k, s in exp.items():
         assert got[k][0] == pytest.approx(s, abs=1e-9), k
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])  # sum / newest arrival wins / oldest arrival wins
+@pytest.mark.parametrize("n_keys,disorder,delay,gap_every,gap_len", [
+    (2, 30, 50, 10**9, 1),     # disorder inside the triggering delay: nothing is dropped, several quanta stay open
+    (2, 30, 10, 10**9, 1),     # ... larger than the delay: late tuples are dropped, by the rules of the tuple-at-a-time engine
+    (3, 40, 0, 10**9, 1),      # no delay at all
+    (40, 25, 30, 300, 200),    # mid-length runs, silences of 20 panes
+    (1, 0, 64, 10**9, 1),      # in order, but windows fire 64 time units late
+    (5, 12, 1000, 700, 90),    # a delay of 100 panes: a large ring of open quanta
+    (3, 900, 20000, 10**9, 1), # ... of 2000 panes: the ring does not fit the LDS and is updated in place
+    (2, 900, 500, 10**9, 1),   # ... disorder of 90 panes, most of it beyond the delay
+])
+def test_key_ffat_time_based_bulk_path_follows_the_sequential_rules(ext, n_keys, disorder, delay, gap_every, gap_len, mode):
+    """Long runs are processed 64 tuples at a time by a wave (prefix maxima of the watermark decide which tuples are late,
+    ordered folds per quantum); runs shorter than 12 tuples take the tuple-at-a-time rules.  Same stream, same results,
+    same number of dropped tuples - also for combines that depend on the arrival order."""
+    n = 24000
+    t, vals = bursty_stream(n, n_keys, seed=77 + n_keys + delay, gap_every=gap_every, gap_len=gap_len, disorder=disorder)
+    res_a, ctr_a = ext.key_ffat_run(t, 80, 10, delay, True, 64, 8192, 1 << 18, mode)
+    res_b, ctr_b = ext.key_ffat_run(t, 80, 10, delay, True, 64, 8 * n_keys, 1 << 18, mode)
+    assert ctr_a["overflow"] == 0 and ctr_b["overflow"] == 0
+    # the late tuples by the rules of the tuple-at-a-time engine (win_seqffat.hpp TB path): a quantum is complete once a
+    # tuple `delay` later than its end has been seen, and the ring of open quanta holds delay / pane + 2 of them
+    pane, late = math.gcd(80, 10), 0
+    ring = 2
+    while ring < delay // pane + 2:
+        ring *= 2
+    for key in np.unique(t[:, 0]):
+        oldest_open = 0
+        for ts in t[t[:, 0] == key, 2]:
+            q = int(ts) // pane
+            if q < oldest_open:
+                late += 1
+                continue
+            done = (int(ts) - delay) // pane if ts > delay else 0
+            oldest_open = max(oldest_open, done, q - ring + 1)
+    assert ctr_a["dropped"] == ctr_b["dropped"] == late
+    a, b = unpack(res_a), unpack(res_b)
+    assert len(a) == len(res_a) and a.keys() == b.keys()
+    for k in a:
+        assert a[k][0] == pytest.approx(b[k][0], abs=1e-9), k
+        assert a[k][1] == b[k][1], k
 
 
 @pytest.mark.parametrize("n_keys,batch", [(3, 2048), (400, 4096)])

@@ -372,8 +372,9 @@ public:
     // key, so the batches go through the device KeyBy in front of the aggregation replicas.
     WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
                    size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr, size_t agg_replicas = 0, int key_dist = 0,
-                   double zipf_alpha = 1.3, bool shared_keys = false)
-        : n_sources_(n_sources), n_sinks_(n_sources), gates_(new wfbench::StepGate[n_sources]), graph_("win_agg_gpu", Mode::DEFAULT) {
+                   double zipf_alpha = 1.3, bool shared_keys = false, bool deterministic = false)
+        : n_sources_(n_sources), n_sinks_(n_sources), gates_(new wfbench::StepGate[n_sources]),
+          graph_("win_agg_gpu", deterministic ? Mode::DETERMINISTIC : Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<SinkTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
@@ -1063,10 +1064,11 @@ PYBIND11_MODULE(_C, m) {
           py::arg("batch_len"), py::arg("n_sources") = 1, py::arg("lanes") = 1, py::arg("max_batches_per_round") = 0);
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
         .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t, int, double,
-                      bool>(),
+                      bool, bool>(),
              py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"),
              py::arg("time_based") = false, py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr,
-             py::arg("agg_replicas") = 0, py::arg("key_dist") = 0, py::arg("zipf_alpha") = 1.3, py::arg("shared_keys") = false)
+             py::arg("agg_replicas") = 0, py::arg("key_dist") = 0, py::arg("zipf_alpha") = 1.3, py::arg("shared_keys") = false,
+             py::arg("deterministic") = false)
         .def("step", &WinAggPipeline::step)
         .def("steps", &WinAggPipeline::steps)
         .def("close", &WinAggPipeline::close)

@@ -195,6 +195,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         idx[i] = src;
     }
 }
+__global__ void det_set_u32_kernel(uint32_t* p, uint32_t v) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p = v;
+}
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS) det_gather_kernel(const T* work, const uint32_t* perm, T* out, uint32_t first, uint32_t count) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) out[i] = work[perm[first + i]];
@@ -741,6 +744,9 @@ private:
             lane_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(tuple_t), lane_cap_, std::max<size_t>(cfg_.pool_slabs, 3) * L));
         }
         const uint64_t base = det_last_w_;
+        uint64_t created = 0;  // oldest tuple of the release (latency accounting downstream)
+        for (const Piece& pc : pieces)
+            if (pc.take > 0 && pc.b->hdr.created_ns != 0) created = created == 0 ? pc.b->hdr.created_ns : std::min(created, pc.b->hdr.created_ns);
         for (size_t l = 0; l < L; l++) {
             size_t n = 0;
             for (const Piece& pc : pieces)
@@ -766,7 +772,7 @@ private:
                 }
                 tables_->template launch<tuple_t>(s);
                 const uint32_t n32 = (uint32_t)n;
-                WF_HIP_CHECK(hipMemcpyAsync(det_n_dev_.data(), &n32, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(gpu::det_set_u32_kernel, dim3(1), dim3(1), 0, s, det_n_dev_.data(), n32);
                 const uint64_t range = hi_ts >= base ? hi_ts - base : 0;
                 int bits = 1;
                 while (bits < 64 && (range >> bits) != 0) bits++;
@@ -798,13 +804,15 @@ private:
                 out->host_hdr.reserved[2] = last ? 0 : hi_ts;
                 out->host_hdr.first_seq = seq_;
                 out->host_hdr.reserved[0] = last ? step_out : 0;
+                out->host_hdr.created_ns = created;
                 out->count_on_host = true;
-                WF_HIP_CHECK(hipMemcpyAsync(out->slab, &out->host_hdr, sizeof(gpu::BatchHeader), hipMemcpyHostToDevice, s));
+                // (the header travels by value in a pinned table; the work and sort buffers are reused by the next lane in stream order)
+                tables_->clear();
+                tables_->hdrs.push_back(gpu::HdrWrite{out->host_hdr, out->header(), {}});
+                tables_->template launch<tuple_t>(s);
                 if (cnt > 0)
                     hipLaunchKernelGGL((gpu::det_gather_kernel<tuple_t>), dim3(gpu::grid_for(cnt)), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), perm,
                                        out->template data<tuple_t>(), (uint32_t)done, (uint32_t)cnt);
-                // the header copy reads host_hdr of this slab and the sort reuses its buffers for the next lane: settle first
-                WF_HIP_CHECK(hipStreamSynchronize(s));
                 out->ready.record(s);
                 emit_to(out, l);
                 xstats_->lane_batches++;

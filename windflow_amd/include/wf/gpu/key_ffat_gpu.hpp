@@ -343,10 +343,14 @@ struct FFATLongLayout {
         if (with_acc.wave_bytes() <= budget) l = with_acc;
         FFATLongLayout with_tree{2 * g.tree_cap, l.acc_slots, 0};
         if (with_tree.wave_bytes() <= budget) l = with_tree;
-        FFATLongLayout with_bulk{2 * FFAT_WORK_LEAVES, acc, 1};
-        if (g.win_panes + WAVE <= FFAT_WORK_LEAVES && with_bulk.wave_bytes() <= budget) l = with_bulk;
-        FFATLongLayout global_bulk{0, acc, 2};
-        if (l.bulk == 0 && g.win_panes + WAVE <= g.tree_cap && global_bulk.wave_bytes() <= budget) l = global_bulk;
+        // bulk paths: with the ring of open quanta staged when it fits (a long triggering delay makes it large), else in place
+        for (const uint32_t a : {acc, 0u}) {
+            if (l.bulk != 0) break;
+            FFATLongLayout with_bulk{2 * FFAT_WORK_LEAVES, a, 1};
+            if (g.win_panes + WAVE <= FFAT_WORK_LEAVES && with_bulk.wave_bytes() <= budget) l = with_bulk;
+            FFATLongLayout global_bulk{0, a, 2};
+            if (l.bulk == 0 && g.win_panes + WAVE <= g.tree_cap && global_bulk.wave_bytes() <= budget) l = global_bulk;
+        }
         return l;
     }
 };
@@ -473,6 +477,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         R* gacc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
         uint8_t* gused = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
         const bool acc_staged = g.is_tb && lay.acc_slots != 0;
+        // the ring as the bulk path sees it (generic pointers: it touches a few slots per chunk)
+        R* racc = acc_staged ? lacc : gacc;
+        uint8_t* rused = acc_staged ? lused : gused;
         if (acc_staged) {
             for (uint32_t k = lane; k < g.acc_cap; k += WAVE) {
                 lacc[k] = gacc[k];
@@ -562,12 +569,44 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             const uint32_t n_segs = (uint32_t)__popcll(bmask);
             // 4. can the whole chunk be handled in bulk?
             bool fast = bulk && cnt > 0;
-            uint64_t q_first = 0, q_last = 0;
+            // time-based: what the sequential rules would do with the chunk, computed for all its tuples at once.
+            //   done_i     quanta below it are complete once tuple i has been seen (its timestamp minus the triggering delay; and
+            //              the ring of open quanta must be able to hold the tuple's own quantum)
+            //   L_i        oldest open quantum when tuple i arrives = max(last_quantum, done_j of the tuples before it)
+            //   late_i     the tuple's quantum is already complete: dropped
+            //   Lq_new     oldest open quantum after the chunk; the m quanta below it are completed by the chunk
+            uint64_t Lq_new = 0, q_max = 0;
+            bool late = false, simple = true;
+            uint32_t n_late = 0;
             if (fast && g.is_tb) {
-                q_first = ((uint64_t)(uint32_t)__shfl((int)hi32, 0, WAVE) << 32) | (uint32_t)__shfl((int)lo32, 0, WAVE);
-                q_last = ((uint64_t)(uint32_t)__shfl((int)hi32, (int)cnt - 1, WAVE) << 32) | (uint32_t)__shfl((int)lo32, (int)cnt - 1, WAVE);
+                const uint64_t Lq = st.last_quantum;
+                uint64_t done = 0;
+                if (ok) {
+                    const uint64_t ts = cf_ts(reg);
+                    done = ts > g.delay ? (ts - g.delay) / g.pane_len : 0;
+                    if (segkey >= done + g.acc_cap) done = segkey - g.acc_cap + 1;
+                }
+                uint64_t pm = done;  // inclusive prefix maximum
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const uint64_t o = wave_shfl_up(pm, d);
+                    if (lane >= d && o > pm) pm = o;
+                }
+                uint64_t before = wave_shfl_up(pm, 1);
+                if (lane == 0 || before < Lq) before = Lq;
+                late = ok && segkey < before;
+                const unsigned long long late_mask = __ballot(late);
+                n_late = (uint32_t)__popcll(late_mask);
+                Lq_new = wave_bcast(pm, WAVE - 1);
+                if (Lq_new < Lq) Lq_new = Lq;
+                uint64_t qm = ok && !late ? segkey : 0;  // newest quantum that received a tuple
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const uint64_t o = wave_shfl_up(qm, d);
+                    if (lane >= d && o > qm) qm = o;
+                }
+                q_max = wave_bcast(qm, WAVE - 1);
                 const bool disorder = __ballot(ok && lane > 0 && segkey < prevkey) != 0;
-                fast = g.delay == 0 && !disorder && q_first >= st.last_quantum && q_last - st.last_quantum <= (uint64_t)WAVE;
+                simple = !disorder && late_mask == 0;  // the segments of the scan above are the chunk's quanta
+                fast = Lq_new - Lq <= (uint64_t)WAVE;    // (a jump in time: the sequential rules know how to skip the empty stretch)
             }
             if (fast) {
                 const auto key = wave_bcast(cf_key(val), 0);
@@ -588,37 +627,81 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     if (rem > 0) st.partial = last_val;
                 } else {
                     const uint64_t Lq = st.last_quantum;
-                    m = (uint32_t)(q_last - Lq);
+                    m = (uint32_t)(Lq_new - Lq);
                     if (pend + m > (uint32_t)WAVE) fire_pending();
                     const uint32_t amask = g.acc_cap - 1;
-                    const bool open_used = lused[(uint32_t)(Lq & amask)] != 0;
-                    // every completed quantum starts as an empty pane ...
+                    // one lane per quantum the chunk touches holds the fold of the chunk's tuples of that quantum, in arrival order
+                    bool qtail = tail;
+                    R qval = val;
+                    if (!simple) {
+                        // tuples out of timestamp order (or late ones in between): the tuples of a quantum are not neighbours.
+                        // One ordered fold over the member lanes per distinct quantum (chunks usually touch two or three).
+                        const R mine = ok ? ffat_lift<T, R, L>(reg, lift) : R{};
+                        qtail = false;
+                        unsigned long long rem = __ballot(ok && !late);
+                        while (rem != 0) {
+                            const int f = __ffsll((long long)rem) - 1;
+                            const uint64_t qs = wave_bcast(segkey, f);
+                            bool has = ok && !late && segkey == qs;
+                            const unsigned long long members = __ballot(has);
+                            R fold = mine;
+                            for (int d = 1; d < WAVE; d <<= 1) {
+                                const R other = wave_shfl_up(fold, d);
+                                const bool ohas = __shfl_up((int)has, d, WAVE) != 0 && lane >= d;
+                                if (ohas) {
+                                    if (has) {
+                                        R tmp;
+                                        fat_combine(comb, other, fold, tmp);
+                                        fold = tmp;
+                                    } else {
+                                        fold = other;
+                                        has = true;
+                                    }
+                                }
+                            }
+                            if (lane == 63 - __builtin_clzll(members)) {
+                                qval = fold;
+                                qtail = true;
+                            }
+                            rem &= ~members;
+                        }
+                    }
+                    // every completed quantum starts from what the ring of open quanta holds for it (or as an empty pane) ...
                     if ((uint32_t)lane < m) {
+                        const uint64_t qq = Lq + (uint64_t)lane;
                         R e{};
-                        if (lane == 0 && open_used) e = lacc[(uint32_t)(Lq & amask)];  // ... except the one that was already open
-                        e.setControlFields(key, Lq + (uint64_t)lane, (Lq + (uint64_t)lane + 1) * g.pane_len - 1);
+                        if ((uint32_t)lane < g.acc_cap && rused[(uint32_t)(qq & amask)]) e = racc[(uint32_t)(qq & amask)];
+                        e.setControlFields(key, qq, (qq + 1) * g.pane_len - 1);
                         wtree[CW + (uint32_t)((P + (uint64_t)lane) & (CW - 1))] = e;
                     }
                     wave_sync_lds();
-                    // ... and the segments overwrite theirs
-                    if (tail) {
-                        const uint32_t x = (uint32_t)(segkey - Lq);
-                        if (x == 0 && open_used) fat_combine(comb, lacc[(uint32_t)(Lq & amask)], val, open_val);
-                        if (x < m) {
-                            R v = open_val;
-                            v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
-                            wtree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
+                    // ... the chunk's tuples of a completed quantum join it ...
+                    if (qtail && segkey < Lq_new) {
+                        const uint32_t x = (uint32_t)(segkey - Lq), a = (uint32_t)(segkey & amask);
+                        R v = qval;
+                        if (x < g.acc_cap && rused[a]) fat_combine(comb, racc[a], qval, v);
+                        v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
+                        wtree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
+                    }
+                    wave_sync_lds();
+                    // ... their slots in the ring are free again ...
+                    if ((uint32_t)lane < m && (uint32_t)lane < g.acc_cap) rused[(uint32_t)((Lq + (uint64_t)lane) & amask)] = 0;
+                    wave_sync_lds();
+                    // ... and the tuples of the quanta that stay open are folded into the ring
+                    if (qtail && segkey >= Lq_new) {
+                        const uint32_t a = (uint32_t)(segkey & amask);
+                        if (rused[a]) {
+                            R tmp;
+                            fat_combine(comb, racc[a], qval, tmp);
+                            racc[a] = tmp;
+                        } else {
+                            racc[a] = qval;
+                            rused[a] = 1;
                         }
                     }
-                    const R last_val = wave_bcast(open_val, (int)cnt - 1);  // quantum q_last stays open
-                    wave_sync_lds();
-                    if (lane == 0) {
-                        for (uint32_t a = 0; a < g.acc_cap; a++) lused[a] = 0;
-                        lacc[(uint32_t)(q_last & amask)] = last_val;
-                        lused[(uint32_t)(q_last & amask)] = 1;
-                    }
-                    st.last_quantum = q_last;
-                    if (q_last + 1 > st.max_quantum) st.max_quantum = q_last + 1;
+                    if (n_late != 0 && lane == 0) atomicAdd(&ctr->dropped, n_late);
+                    st.last_quantum = Lq_new;
+                    if (n_late < cnt && q_max + 1 > st.max_quantum) st.max_quantum = q_max + 1;
                 }
                 st.seen = 1;
                 st.panes = P + m;
