@@ -470,6 +470,26 @@ def test_key_ffat_huge_runs_time_based(ext, n, n_cold, share, win, slide, batch,
         assert got[k][0] == pytest.approx(s, abs=1e-9), k
 
 
+@pytest.mark.parametrize("win,slide,delay,ts_step,batch", [
+    (64, 16, 16, 1, 8192),        # one pane of delay: two quanta open
+    (64, 16, 200, 1, 8192),       # 12 panes of delay
+    (400, 100, 250, 2, 16384),
+    (3000, 10, 95, 1, 8192),      # long windows (block prefix / suffix folds), 10 quanta open
+    (5000, 5000, 20000, 1, 8192), # tumbling, delay of four windows
+])
+def test_key_ffat_huge_runs_time_based_with_triggering_delay(ext, win, slide, delay, ts_step, batch):
+    """in-order hot keys with a triggering delay: the newest quanta of a run stay open in the key's ring"""
+    t, vals = hot_stream(100_000, 3, 0.6, seed=win + delay, ts_step=ts_step)
+    res, ctr = ext.key_ffat_run(t, win, slide, delay, True, 16, batch, 1 << 19)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    assert ctr["huge_runs"] > 0
+    got = unpack(res)
+    exp = oracle_tb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, s in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9), k
+
+
 def test_key_ffat_huge_runs_with_disorder_fall_back(ext):
     """a hot key whose tuples are not in timestamp order (delay 0: the late ones are dropped, by the same rules as a short run)"""
     t, vals = hot_stream(80_000, 20, 0.7, seed=17)

@@ -22,8 +22,9 @@
 //                                one combine whatever W is, and the order of the panes is kept (the combine need not commute)
 //   6. ffat_huge_windows_kernel  one thread per fired window: that one combine, or for short windows a fold over the W leaves
 //                                (old panes of the key in front, new ones behind)
-// Used for count-based windows and for time-based windows without triggering delay whose run is in timestamp order and not
-// sparse in time; everything else goes to the wave-per-run kernel, which implements the full rules.  The engine switches these five launches on when a batch shows a huge run and off again after
+// Used for count-based windows and for time-based windows whose run is in timestamp order, not late and not sparse in time
+// (with a triggering delay the newest quanta of the run stay open in the key's ring instead of becoming leaves); everything
+// else goes to the wave-per-run kernel, which implements the full rules.  The engine switches these five launches on when a batch shows a huge run and off again after
 // a while without one (key_ffat_gpu.hpp), so streams without hot keys do not pay for them.
 //
 // Reference: the reference engine (wf/win_seqffat_gpu.hpp:369-396 + wf/flatfat_gpu.hpp:251-434) handles ONE key per replica
@@ -57,14 +58,17 @@ struct FFATHugeRun {
     uint32_t leaf_base;   // first leaf of the run in the scratch: win_panes - 1 old panes, then the panes of the run
     uint32_t max_panes, pc0;
     uint64_t P0, Lq, first_lwid;
+    uint64_t Lq_new;  // time-based: oldest quantum that stays open after the run (the quanta below it are completed by it)
     uint32_t m, nf, out_base, fallback;
 };
 
 template <typename T, typename R>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_setup_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const FFATKeyState<R>* states,
-                           uint64_t pane_len, uint32_t is_tb, uint32_t win_panes, const uint32_t* huge_heads, const uint32_t* n_huge, FFATHugeRun* runs,
-                           FFATHugeCtl* ctl, uint32_t max_runs, uint32_t leaves_cap) {
+                           FFATGeometry g, const uint32_t* huge_heads, const uint32_t* n_huge, FFATHugeRun* runs, FFATHugeCtl* ctl, uint32_t max_runs,
+                           uint32_t leaves_cap) {
+    const uint64_t pane_len = g.pane_len;
+    const uint32_t is_tb = g.is_tb, win_panes = g.win_panes;
     const uint32_t n = hdr->count;
     uint32_t nr = *n_huge;
     if (nr > max_runs) nr = max_runs;
@@ -93,10 +97,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             const uint64_t q0 = cf_ts(data[sidx[hr.head]]) / pane_len, q1 = cf_ts(data[sidx[hr.head + hr.len - 1]]) / pane_len;
             // late tuples, disorder across the run, or a run that is sparse in time (more panes than tuples: most windows are
             // empty): the sequential rules handle them
-            if (q0 < hr.Lq || q1 < q0 || q1 - hr.Lq > (uint64_t)hr.len + WAVE)
+            if (q0 < hr.Lq || q1 < q0 || q1 - hr.Lq > (uint64_t)hr.len + WAVE + g.acc_cap) {
                 hr.fallback = 1;
-            else
+            } else {
                 hr.max_panes = (uint32_t)(q1 - hr.Lq) + 1;
+                // the run is in timestamp order (the chunks check it): its last tuple decides what is complete afterwards
+                const uint64_t ts1 = cf_ts(data[sidx[hr.head + hr.len - 1]]);
+                uint64_t done = ts1 > g.delay ? (ts1 - g.delay) / pane_len : 0;
+                if (q1 >= done + g.acc_cap) done = q1 - g.acc_cap + 1;  // the ring of open quanta must hold the newest one
+                hr.Lq_new = done > hr.Lq ? done : hr.Lq;
+            }
         }
         runs[r] = hr;
     }
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_chunks_kernel(const T* data, const uint32_t* sidx, uint64_t pane_len, uint32_t is_tb, uint32_t win_panes, FFATHugeRun* runs,
-                            const FFATHugeCtl* ctl, FFATPartial<R>* parts, R* leaves, L lift, C comb) {
+                            const FFATHugeCtl* ctl, FFATPartial<R>* parts, R* leaves, uint8_t* leaf_has, L lift, C comb) {
     const uint32_t total = ctl->total_chunks, nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -199,6 +209,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 R v = val;
                 if (is_tb) v.setControlFields(cf_key(val), hr.Lq + pane, (hr.Lq + pane + 1) * pane_len - 1);
                 leaves[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)pane] = v;
+                if (is_tb) leaf_has[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)pane] = 1;
             }
         }
         if (lane == 0 && n_segs < 2) {
@@ -213,6 +224,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     R e{};
                     e.setControlFields(cf_key(val), hr.Lq + q, (hr.Lq + q + 1) * pane_len - 1);
                     leaves[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)q] = e;
+                    leaf_has[(size_t)hr.leaf_base + (win_panes - 1) + (uint32_t)q] = 0;
                 }
             }
         }
@@ -267,7 +279,7 @@ __device__ __forceinline__ FFATStitched<R> ffat_stitch_wave(bool ok, uint32_t pa
 template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_stitch_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const FFATPartial<R>* parts, FFATPartial<R>* parts2,
-                            R* leaves, const unsigned long long* table, C comb) {
+                            R* leaves, uint8_t* leaf_has, const unsigned long long* table, C comb) {
     const uint32_t total = ctl->total_units, nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -291,6 +303,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         using key_t = decltype(cf_key(pe.val));
         const key_t key = (key_t)table[hr.slot];
         R* lv = leaves + (size_t)hr.leaf_base + (g.win_panes - 1);
+        uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (g.win_panes - 1);
         FFATPartial<R>* mine = parts2 + 2 * (size_t)u;
         if (st.tail) {
             if (st.seg == 0 || st.seg == st.n_segs - 1) {
@@ -302,6 +315,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 R x = st.val;
                 if (g.is_tb) x.setControlFields(key, hr.Lq + pe.pane, (hr.Lq + pe.pane + 1) * g.pane_len - 1);
                 lv[pe.pane] = x;
+                if (g.is_tb) lh[pe.pane] = 1;
             }
         }
         if (lane == 0 && st.n_segs < 2) {
@@ -315,6 +329,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 R x{};
                 x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
                 lv[p] = x;
+                lh[p] = 0;
             }
         }
     }
@@ -323,8 +338,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
-                         const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint32_t* out_count, uint32_t* long_heads, uint32_t* n_long,
-                         const unsigned long long* table, FFATCounters* ctr, C comb) {
+                         const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint8_t* leaf_has, uint32_t* out_count, uint32_t* long_heads,
+                         uint32_t* n_long, const unsigned long long* table, FFATCounters* ctr, C comb) {
     const uint32_t nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -338,6 +353,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         FFATKeyState<R> st = states[hr.slot];
         R* gtree = trees + (size_t)hr.slot * 2 * g.tree_cap;
         R* lv = leaves + (size_t)hr.leaf_base + (W - 1);  // lv[p] = pane P0 + p
+        uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (W - 1);  // time-based: the pane received tuples (else it is a place holder)
         using key_t = decltype(cf_key(st.partial));
         const key_t key = (key_t)table[hr.slot];
         // the panes a window fired by this run can still need, in front of the new ones
@@ -346,39 +362,34 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             // (the key's first windows: the panes before pane 0 do not exist; no window reaches them, the block scans may)
             lv[-(int64_t)back] = hr.P0 >= back ? gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))] : R{};
         }
-        // what was open before the run is the head of pane 0 (the carry is kept identical in every lane)
+        // count-based: what was open before the run is the head of pane 0 (the carry is kept identical in every lane).
+        // time-based: the quanta that were open before the run (the key's ring) are joined with the run's panes afterwards
         bool c_has = false;
         uint32_t c_pane = 0;
         R c_val{};
         R* acc = g.is_tb ? accs + (size_t)hr.slot * g.acc_cap : nullptr;
         uint8_t* used = g.is_tb ? acc_used + (size_t)hr.slot * g.acc_cap : nullptr;
-        if (!g.is_tb) {
-            if (hr.pc0 > 0) {
-                c_has = true;
-                c_val = st.partial;
-            }
-        } else {
-            const uint32_t a = (uint32_t)(hr.Lq & (g.acc_cap - 1));
-            if (used[a]) {
-                c_has = true;
-                c_val = acc[a];
-            }
+        if (!g.is_tb && hr.pc0 > 0) {
+            c_has = true;
+            c_val = st.partial;
         }
-        wave_sync_lds();
-        if (g.is_tb && lane == 0)
-            for (uint32_t a = 0; a < g.acc_cap; a++) used[a] = 0;
         auto put_leaf = [&](uint32_t p, const R& v) {
             R x = v;
-            if (g.is_tb) x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+            if (g.is_tb) {
+                x.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+                lh[p] = 1;
+            }
             lv[p] = x;
+        };
+        auto put_empty = [&](uint32_t p) {
+            R e{};
+            e.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
+            lv[p] = e;
+            lh[p] = 0;
         };
         // time-based: panes [from, to) received nothing (whole wave)
         auto fill_gap = [&](uint32_t from, uint32_t to) {
-            for (uint32_t p = from + (uint32_t)lane; p < to; p += WAVE) {
-                R e{};
-                e.setControlFields(key, hr.Lq + p, (hr.Lq + p + 1) * g.pane_len - 1);
-                lv[p] = e;
-            }
+            for (uint32_t p = from + (uint32_t)lane; p < to; p += WAVE) put_empty(p);
         };
         const uint32_t n_entries = 2 * hr.n_units;
         for (uint32_t e0 = 0; e0 < n_entries; e0 += WAVE) {
@@ -401,7 +412,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             }
             if (sw.tail && sw.seg < sw.n_segs - 1) put_leaf(pe.pane, sw.val);
             if (g.is_tb && sw.boundary && lane > 0 && (e & 1u) == 0)
-                for (uint32_t p = sw.prev_pane + 1; p < pe.pane; p++) put_leaf(p, R{});
+                for (uint32_t p = sw.prev_pane + 1; p < pe.pane; p++) put_empty(p);
             // the last segment is the new carry
             const int last = (int)sw.cnt - 1;
             c_val = wave_bcast(sw.val, last);
@@ -409,6 +420,30 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             c_has = true;
         }
         wave_sync_lds();
+        if (g.is_tb) {
+            // The run's panes 0 .. c_pane are quanta Lq .. Lq + c_pane.  Join them with what the key's ring held for these quanta,
+            // then the quanta below Lq_new are complete (leaves) and the others go (back) to the ring.
+            const uint32_t amask = g.acc_cap - 1, n_p = c_pane + 1, m_tb = (uint32_t)(hr.Lq_new - hr.Lq);
+            if (lane == 0) put_leaf(c_pane, c_val);
+            wave_sync_lds();
+            for (uint32_t p = (uint32_t)lane; p < n_p && p < g.acc_cap; p += WAVE) {
+                const uint32_t a = (uint32_t)((hr.Lq + p) & amask);
+                if (used[a]) {
+                    R x = acc[a];
+                    if (lh[p]) fat_combine(comb, acc[a], lv[p], x);
+                    put_leaf(p, x);
+                }
+            }
+            wave_sync_lds();
+            for (uint32_t p = (uint32_t)lane; p < m_tb && p < g.acc_cap; p += WAVE) used[(uint32_t)((hr.Lq + p) & amask)] = 0;
+            wave_sync_lds();
+            for (uint32_t p = m_tb + (uint32_t)lane; p < n_p; p += WAVE) {  // (at most acc_cap quanta: see the set-up kernel)
+                const uint32_t a = (uint32_t)((hr.Lq + p) & amask);
+                if (lh[p]) acc[a] = lv[p];
+                used[a] = lh[p];
+            }
+            wave_sync_lds();
+        }
         // the last pane of the run: complete (count-based, when the run ends on a pane boundary) or left open
         uint32_t m = 0;
         if (lane == 0) {
@@ -424,12 +459,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     st.pcount = rem;
                 }
             } else {
-                m = c_pane;  // quantum Lq + c_pane stays open
+                m = (uint32_t)(hr.Lq_new - hr.Lq);  // the quanta from Lq_new on stay open
                 const uint64_t q1 = hr.Lq + c_pane;
-                const uint32_t a = (uint32_t)(q1 & (g.acc_cap - 1));
-                acc[a] = c_val;
-                used[a] = 1;
-                st.last_quantum = q1;
+                st.last_quantum = hr.Lq_new;
                 if (q1 + 1 > st.max_quantum) st.max_quantum = q1 + 1;
             }
             st.seen = 1;

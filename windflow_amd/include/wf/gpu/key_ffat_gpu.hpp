@@ -900,17 +900,18 @@ public:
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
         n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
         WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
-        // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones without a triggering delay
-        huge_ok_ = (!g_.is_tb || delay == 0) && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
+        // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones whose ring of open quanta is not enormous
+        huge_ok_ = (!g_.is_tb || g_.acc_cap <= 8192) && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
         if (huge_ok_) {
             huge_max_runs_ = (uint32_t)(batch_cap_ / FFAT_HUGE_RUN + 1);
-            huge_leaves_cap_ = (uint32_t)(batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70));
+            huge_leaves_cap_ = (uint32_t)(batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70 + (g_.is_tb ? g_.acc_cap : 0)));
             huge_heads_.resize(huge_max_runs_);
             huge_runs_.resize(huge_max_runs_);
             huge_ctl_.resize(1);
             huge_parts_.resize(2 * (batch_cap_ / WAVE + huge_max_runs_));
             huge_parts2_.resize(2 * (2 * (batch_cap_ / WAVE + huge_max_runs_) / WAVE + huge_max_runs_));
             huge_leaves_.resize(huge_leaves_cap_);
+            if (g_.is_tb) huge_has_.resize(huge_leaves_cap_);
             if (g_.win_panes > FFAT_HUGE_DIRECT_WIN) {
                 huge_pre_.resize(huge_leaves_cap_);
                 huge_suf_.resize(huge_leaves_cap_);
@@ -1003,19 +1004,19 @@ private:
                                comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_);
             if (huge_mode == 2) {
                 hipLaunchKernelGGL((ffat_huge_setup_kernel<T, R>), dim3(1), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys,
-                                   sorted.vals, states_.data(), g_.pane_len, g_.is_tb, g_.win_panes, huge_heads_.data(), n_long_.data() + 1,
-                                   huge_runs_.data(), huge_ctl_.data(), huge_max_runs_, huge_leaves_cap_);
+                                   sorted.vals, states_.data(), g_, huge_heads_.data(), n_long_.data() + 1, huge_runs_.data(), huge_ctl_.data(),
+                                   huge_max_runs_, huge_leaves_cap_);
                 const unsigned cgrid = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (upper / WAVE + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
                 hipLaunchKernelGGL((ffat_huge_chunks_kernel<T, R, L, C>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, in->template data<T>(), sorted.vals,
                                    g_.pane_len, g_.is_tb, g_.win_panes, huge_runs_.data(), huge_ctl_.data(), huge_parts_.data(), huge_leaves_.data(),
-                                   lift_, comb_);
+                                   huge_has_.data(), lift_, comb_);
                 const unsigned sgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (upper / WAVE / 32 + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
                 hipLaunchKernelGGL((ffat_huge_stitch_kernel<R, C>), dim3(sgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
-                                   huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), table_.data(), comb_);
+                                   huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), huge_has_.data(), table_.data(), comb_);
                 const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
                                    acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
-                                   out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
+                                   huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
                 const bool hgw = g_.win_panes > FFAT_HUGE_DIRECT_WIN;
                 if (hgw) {
                     // two work items per block of win_panes leaves, a wave each
@@ -1102,6 +1103,7 @@ private:
     DeviceBuffer<FFATHugeCtl> huge_ctl_;
     DeviceBuffer<FFATPartial<R>> huge_parts_, huge_parts2_;
     DeviceBuffer<R> huge_leaves_, huge_pre_, huge_suf_;
+    DeviceBuffer<uint8_t> huge_has_;
     // hipGraph cache
     struct GraphKey {
         const void* in;
