@@ -46,7 +46,10 @@ def parse_args():
                         "campaign; with --parallelism keyby the campaigns are partitioned across the GPUs by Exchange_GPU); map_filter: "
                         "stateless Map_GPU+Filter_GPU")
     p.add_argument("--ysb-period-us", type=int, default=1, help="ysb: event-time distance between two events of a source")
-    p.add_argument("--ysb-delay-us", type=int, default=1000000, help="ysb: triggering delay of the windows (tolerated lag between sources)")
+    p.add_argument("--ysb-delay-us", type=int, default=10000000,
+                   help="ysb: triggering delay of the windows = tolerated lag between the event sources, of this GPU and of the others "
+                        "(default: one window; the sources of a process advance at most 4 batches apart, the processes are only coupled by "
+                        "the exchange).  Late events are counted in config.dropped")
     p.add_argument("--ysb-split-merge", action="store_true",
                    help="ysb: split the events on the device by ad type into two filter+join branches and merge them again in front of the "
                         "aggregation (the split/merge PipeGraph of BASELINE config 5)")

@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -82,6 +83,34 @@ struct StepGate {
         }
         cv.notify_all();
     }
+};
+
+// Sources that emit the SAME keys stand for readers of one time-ordered feed: they advance together.  Without this the
+// synthetic clocks (a timestamp is a sequence number) of two source threads drift apart by whatever the scheduler does to
+// them, and a time-based window downstream sees tuples that are "late" by an arbitrary amount.  A source may be at most
+// `slack` batches ahead of the slowest one.
+struct SkewBound {
+    SkewBound(size_t n, uint64_t slack_batches) : n(n), slack(slack_batches), done(new std::atomic<uint64_t>[n]) {
+        for (size_t i = 0; i < n; i++) done[i].store(0, std::memory_order_relaxed);
+    }
+    // before source i generates its next batch; `gate` is the source's own gate (a shutdown ends the wait)
+    void wait_turn(size_t i, StepGate& gate) {
+        const uint64_t mine = done[i].load(std::memory_order_relaxed);
+        for (unsigned spins = 0;; spins++) {
+            uint64_t slowest = UINT64_MAX;
+            for (size_t j = 0; j < n; j++) slowest = std::min(slowest, done[j].load(std::memory_order_acquire));
+            if (mine < slowest + slack) return;
+            if ((spins & 63) == 63) {
+                std::lock_guard<std::mutex> l(gate.m);
+                if (gate.stop) return;
+            }
+            std::this_thread::yield();
+        }
+    }
+    void batch_done(size_t i) { done[i].fetch_add(1, std::memory_order_release); }
+    size_t n;
+    uint64_t slack;
+    std::unique_ptr<std::atomic<uint64_t>[]> done;
 };
 
 struct StepBarrier {
@@ -185,6 +214,7 @@ public:
             g.quota -= take;
             if (g.quota == 0) punct_ = g.step_id;  // last batch of the step
         }
+        if (skew_) skew_->wait_turn(ctx.getReplicaIndex(), g);
         opened_ns_ = wf::current_time_nsecs();
         const uint64_t src = ctx.getReplicaIndex() + src_offset_;
         uint64_t seq = seq_, kc = kc_, round = round_;
@@ -233,14 +263,18 @@ public:
         round_ = round;
         rng_ = rng;
         n = (size_t)take;
+        if (skew_) skew_->batch_done(ctx.getReplicaIndex());
         return true;
     }
+    // sources that share keys advance together (SkewBound); call before the generator is copied into the source replicas
+    void bound_skew(std::shared_ptr<SkewBound> s) { skew_ = std::move(s); }
     // Batch_Source hook: non-zero closes a step
     uint64_t punctuation() const { return punct_; }
     // Batch_Source hook: when the first tuple of the batch was generated
     uint64_t opened_ns() const { return opened_ns_; }
 
 private:
+    std::shared_ptr<SkewBound> skew_;
     StepGate* gates_;
     KeySpace keys_;
     size_t n_keys_;

@@ -380,6 +380,8 @@ public:
         const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
         wfbench::GatedGenerator gen(gates_.get(), wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys), 1,
                                     n_sources, rank * n_sources, world * n_sources);
+        // sources that emit the same keys read one feed: at most 4 batches apart (bench_common.hpp SkewBound)
+        if (shared_keys) gen.bound_skew(std::make_shared<wfbench::SkewBound>(n_sources, 4));
         source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
                       .withGPUConfiguration(gpu_id).build_unique();
         MultiPipe& mp = graph_.add_source(*source_);
@@ -754,6 +756,7 @@ public:
             g.quota -= take;
             if (g.quota == 0) punct_ = g.step_id;
         }
+        if (skew_) skew_->wait_turn(ctx.getReplicaIndex(), g);
         opened_ns_ = wf::current_time_nsecs();
         uint64_t v = value_;
         const uint64_t* ads = ads_->data();
@@ -771,12 +774,16 @@ public:
         }
         value_ = v;
         n = (size_t)take;
+        if (skew_) skew_->batch_done(ctx.getReplicaIndex());
         return true;
     }
     uint64_t punctuation() const { return punct_; }
     uint64_t opened_ns() const { return opened_ns_; }
+    // every source emits every campaign: the sources of a process advance together (bench_common.hpp SkewBound)
+    void bound_skew(std::shared_ptr<wfbench::SkewBound> s) { skew_ = std::move(s); }
 
 private:
+    std::shared_ptr<wfbench::SkewBound> skew_;
     wfbench::StepGate* gates_;
     uint64_t period_;
     size_t n_ads_;
@@ -800,7 +807,9 @@ public:
         auto totals = totals_ = std::make_shared<YsbTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
-        source_ = BatchSource_Builder(GatedEventSource(gates_.get(), &campaigns_, period_us)).withName("ysb_source").withParallelism(n_sources)
+        GatedEventSource events(gates_.get(), &campaigns_, period_us);
+        events.bound_skew(std::make_shared<wfbench::SkewBound>(n_sources, 4));
+        source_ = BatchSource_Builder(events).withName("ysb_source").withParallelism(n_sources)
                       .withBatch(batch_len).withInFlightBatches(inflight).withGPUConfiguration(gpu_id).build_unique();
         MultiPipe* mp = &graph_.add_source(*source_);
         const size_t branches = split_merge ? 2 : 1;
