@@ -97,6 +97,8 @@ def check(res, ctr, exp):
     (30000, 3, 1000, 999, 2048, 3),    # long windows that span many batches
     (20000, 4, 7, 7, 1000, 0),         # tumbling
     (20000, 5, 3, 10, 777, 3),         # hopping: 7 of 10 tuples fall in the gaps
+    (60000, 3000, 200, 50, 4096, 0),   # one or two tuples of a key per batch, a window every ~35 batches: runs appended in place
+    (60000, 3000, 64, 1, 4096, 3),     # ... and a window per tuple once the first one is full
 ])
 def test_count_based_windows_match_oracle(ext, n, n_keys, win, slide, batch, mode):
     t, vals = make_stream(n, n_keys, seed=n + win)
@@ -105,7 +107,8 @@ def test_count_based_windows_match_oracle(ext, n, n_keys, win, slide, batch, mod
     check(res, ctr, oracle(t, vals, win, slide, False, mode))
 
 
-@pytest.mark.parametrize("n,n_keys,win,slide,batch", [(20000, 9, 10, 3, 512), (30000, 1, 256, 32, 4096), (30000, 2000, 6, 2, 8192)])
+@pytest.mark.parametrize("n,n_keys,win,slide,batch", [(20000, 9, 10, 3, 512), (30000, 1, 256, 32, 4096), (30000, 2000, 6, 2, 8192),
+                                                      (60000, 2500, 300, 100, 2048)])
 def test_count_based_renumbering_ignores_ids(ext, n, n_keys, win, slide, batch):
     """batch-fed streams: the tuples of a key are numbered by arrival on the device"""
     t, vals = make_stream(n, n_keys, seed=n, per_key_ids=False)
@@ -119,6 +122,7 @@ def test_count_based_renumbering_ignores_ids(ext, n, n_keys, win, slide, batch):
     (20000, 40, 900, 600, 8192, 3),
     (20000, 6, 300, 1000, 1500, 1),   # hopping
     (20000, 3, 500, 500, 2048, 2),    # tumbling
+    (60000, 2000, 6000, 2000, 2048, 1),  # a tuple of a key per batch, a window every 60 batches or so
 ])
 def test_time_based_windows_match_oracle(ext, n, n_keys, win, slide, batch, ts_step):
     t, vals = make_stream(n, n_keys, seed=n + slide, ts_step=ts_step)

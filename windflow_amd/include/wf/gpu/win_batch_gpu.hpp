@@ -171,10 +171,16 @@ __device__ __forceinline__ uint32_t win_lower_bound(const T* seg, uint32_t n, ui
 }
 
 // ---- 2. run table ------------------------------------------------------------------------------
+// Short runs that fire no window (many keys, a few tuples of each per batch, a window every so many batches) do not enter the
+// table: their tuples are APPENDED to the key's carry area by the thread that found the run.  Only a batch that completes a
+// window of the key pays for gathering the carried tuples into a contiguous segment (and for writing the tail back).
+constexpr uint32_t WB_QUIET_RUN = 16;       // longest run appended in place
+constexpr uint32_t WB_NO_RUN = 0xffffffffu;  // WinKeyState::cur_run of a key whose run was appended
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_runs_kernel(const BatchHeader* hdr, const uint32_t* sslot, const unsigned long long* table, WinKeyState* states, WinRun* runs,
-                   uint32_t* work_len, WinCtl* ctl, WinCounters* ctr, WinGeometry g) {
+    wb_runs_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const unsigned long long* table,
+                   WinKeyState* states, WinRun* runs, uint32_t* work_len, T* carry, WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t quiet_ok) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
@@ -209,9 +215,40 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             atomicAdd(&ctr->table_full, len);
             continue;
         }
+        const WinAssignD wa = win_assign(g, (uint64_t)table[slot]);
+        if (quiet_ok && len <= WB_QUIET_RUN && st.carry_len + len <= g.carry_cap && g.win >= g.slide) {
+            // in order (also against what is carried), not late, and no window of the key ends with these tuples?
+            T* area = carry + (size_t)st.dense * g.carry_cap;
+            const uint64_t keep_from = wa.initial_id + st.next_lwid * g.slide;
+            uint64_t prev = st.carry_len > 0 ? win_ord(area[st.carry_len - 1], g.is_tb) : ((st.next_lwid > 0) ? keep_from : 0);
+            bool quiet = true;
+            if (g.renumber) {
+                prev = st.count + len - 1;
+            } else {
+                for (uint32_t k = 0; k < len && quiet; k++) {
+                    const uint64_t o = win_ord(data[sidx[i + k]], g.is_tb);
+                    quiet = o >= prev;
+                    prev = o;
+                }
+            }
+            const uint64_t max_ord = (st.flags & 1u) && st.max_ord > prev ? st.max_ord : prev;
+            if (quiet && win_fired_upto(g, wa.initial_id, max_ord) <= st.next_lwid) {
+                for (uint32_t k = 0; k < len; k++) {
+                    T t = data[sidx[i + k]];
+                    if (g.renumber) t.setControlFields(cf_key(t), st.count + k, cf_ts(t));
+                    area[st.carry_len + k] = t;
+                }
+                WinKeyState* ks = &states[slot];
+                ks->max_ord = max_ord;
+                ks->count = st.count + len;
+                ks->carry_len = st.carry_len + len;
+                ks->flags = st.flags | 1u;
+                ks->cur_run = WB_NO_RUN;
+                continue;
+            }
+        }
         const uint32_t r = atomicAdd(&ctl->n_runs, 1u);
         states[slot].cur_run = r;
-        const WinAssignD wa = win_assign(g, (uint64_t)table[slot]);
         WinRun run;
         run.slot = slot;
         run.start = i;
@@ -255,6 +292,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const WinKeyState* st = &states[slot];
         if (st->dense >= g.max_keys) continue;
         const uint32_t r = st->cur_run;
+        if (r == WB_NO_RUN) continue;  // appended to the key's carry area by wb_runs_kernel
         const uint32_t start = runs[r].start, clen = runs[r].carry_len;
         const uint32_t dst = work_off[r] + clen + (j - start);
         if (dst >= g.work_cap) {
@@ -782,6 +820,7 @@ public:
             if (const char* e = std::getenv("WF_WIN_TILE")) {
                 if (std::atoi(e) == 0) tile_group_ = 0;
             }
+            if (const char* e = std::getenv("WF_WIN_QUIET_RUNS")) quiet_runs_ = std::atoi(e) != 0;
         }
         init.sync();
         sorter_.reserve(batch_cap_);
@@ -815,8 +854,9 @@ public:
                            (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyFn{}, out->header(),
                            &ctl_.data()->n_runs);
         const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
-        hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), sorted.keys, table_.data(), states_.data(),
-                           runs_.data(), work_len_.data(), ctl_.data(), counters_.data(), g_);
+        hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
+                           table_.data(), states_.data(), runs_.data(), work_len_.data(), carry_.data(), ctl_.data(), counters_.data(), g_,
+                           quiet_runs_ ? 1u : 0u);
         exclusive_scan_u32(work_len_.data(), work_off_.data(), runs_upper, &ctl_.data()->work_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
         hipLaunchKernelGGL((wb_gather_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
                            states_.data(), runs_.data(), work_off_.data(), carry_.data(), work_.data(), ctl_.data(), counters_.data(), g_);
@@ -910,6 +950,7 @@ private:
     size_t table_cap_ = 0, batch_cap_ = 0, n_tab_ = 0;
     int slot_bits_ = 0;
     uint32_t tile_group_ = 0;
+    bool quiet_runs_ = true;  // short runs that fire no window are appended to the carry areas in place (wb_runs_kernel)
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<WinKeyState> states_;
     DeviceBuffer<T> carry_, work_;
