@@ -90,16 +90,23 @@ struct StepGate {
 // them, and a time-based window downstream sees tuples that are "late" by an arbitrary amount.  A source may be at most
 // `slack` batches ahead of the slowest one.
 struct SkewBound {
-    SkewBound(size_t n, uint64_t slack_batches) : n(n), slack(slack_batches), done(new std::atomic<uint64_t>[n]) {
-        for (size_t i = 0; i < n; i++) done[i].store(0, std::memory_order_relaxed);
+    SkewBound(size_t n, uint64_t slack_batches) : n(n), slack(slack_batches), own(new std::atomic<uint64_t>[n]) {
+        for (size_t i = 0; i < n; i++) own[i].store(0, std::memory_order_relaxed);
+        rows.push_back(own.get());
+        mine = own.get();
     }
+    // sources of several ranks: row r holds the counters of rank r's n sources (shared memory: the control board of the
+    // ranks' transport); this process advances row `rank`
+    SkewBound(std::vector<std::atomic<uint64_t>*> rank_rows, size_t rank, size_t n, uint64_t slack_batches)
+        : n(n), slack(slack_batches), rows(std::move(rank_rows)), mine(rows[rank]) {}
     // before source i generates its next batch; `gate` is the source's own gate (a shutdown ends the wait)
     void wait_turn(size_t i, StepGate& gate) {
-        const uint64_t mine = done[i].load(std::memory_order_relaxed);
+        const uint64_t me = mine[i].load(std::memory_order_relaxed);
         for (unsigned spins = 0;; spins++) {
             uint64_t slowest = UINT64_MAX;
-            for (size_t j = 0; j < n; j++) slowest = std::min(slowest, done[j].load(std::memory_order_acquire));
-            if (mine < slowest + slack) return;
+            for (std::atomic<uint64_t>* row : rows)
+                for (size_t j = 0; j < n; j++) slowest = std::min(slowest, row[j].load(std::memory_order_acquire));
+            if (me < slowest + slack) return;
             if ((spins & 63) == 63) {
                 std::lock_guard<std::mutex> l(gate.m);
                 if (gate.stop) return;
@@ -107,10 +114,12 @@ struct SkewBound {
             std::this_thread::yield();
         }
     }
-    void batch_done(size_t i) { done[i].fetch_add(1, std::memory_order_release); }
+    void batch_done(size_t i) { mine[i].fetch_add(1, std::memory_order_release); }
     size_t n;
     uint64_t slack;
-    std::unique_ptr<std::atomic<uint64_t>[]> done;
+    std::unique_ptr<std::atomic<uint64_t>[]> own;
+    std::vector<std::atomic<uint64_t>*> rows;
+    std::atomic<uint64_t>* mine;
 };
 
 struct StepBarrier {

@@ -363,6 +363,15 @@ static void exchange_stats(py::dict& d, const ExchangeStats& x, size_t lanes) {
 
 // S gated batch sources -> Key_FFAT_GPU (device-resident keyed sliding-window sum) -> D2H -> batch sinks
 // (BASELINE.json config 4, the flagship "sliding-window aggregation" pipeline)
+// sources that emit the same keys advance together: within the process, and across the ranks of a transport through the
+// progress counters of its control board (bench_common.hpp SkewBound)
+static std::shared_ptr<wfbench::SkewBound> make_skew_bound(const std::shared_ptr<dist::Transport>& tr, size_t n_sources) {
+    if (!tr || tr->world() == 1 || n_sources > (size_t)dist::ControlBoard::PROGRESS_LANES) return std::make_shared<wfbench::SkewBound>(n_sources, 4);
+    std::vector<std::atomic<uint64_t>*> rows;
+    for (int r = 0; r < tr->world(); r++) rows.push_back(tr->board().progress(r));
+    return std::make_shared<wfbench::SkewBound>(std::move(rows), (size_t)tr->rank(), n_sources, 8);
+}
+
 class WinAggPipeline {
 public:
     // transport == nullptr: every source lane feeds its own Key_FFAT_GPU replica (keys are partitioned at the
@@ -381,7 +390,7 @@ public:
         wfbench::GatedGenerator gen(gates_.get(), wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys), 1,
                                     n_sources, rank * n_sources, world * n_sources);
         // sources that emit the same keys read one feed: at most 4 batches apart (bench_common.hpp SkewBound)
-        if (shared_keys) gen.bound_skew(std::make_shared<wfbench::SkewBound>(n_sources, 4));
+        if (shared_keys) gen.bound_skew(make_skew_bound(transport, n_sources));
         source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
                       .withGPUConfiguration(gpu_id).build_unique();
         MultiPipe& mp = graph_.add_source(*source_);
@@ -808,7 +817,7 @@ public:
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
         GatedEventSource events(gates_.get(), &campaigns_, period_us);
-        events.bound_skew(std::make_shared<wfbench::SkewBound>(n_sources, 4));
+        events.bound_skew(make_skew_bound(transport, n_sources));
         source_ = BatchSource_Builder(events).withName("ysb_source").withParallelism(n_sources)
                       .withBatch(batch_len).withInFlightBatches(inflight).withGPUConfiguration(gpu_id).build_unique();
         MultiPipe* mp = &graph_.add_source(*source_);

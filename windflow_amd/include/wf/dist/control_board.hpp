@@ -51,6 +51,7 @@ class ControlBoard {
 public:
     static constexpr uint64_t DEPTH = 8;
     static constexpr size_t GATHER_WORDS = 64;
+    static constexpr int PROGRESS_LANES = 16;  // sources per rank with a progress counter on the board
     struct Slot {
         std::atomic<uint64_t> tag;  // round + 1 when the row is valid
         ControlRow row;
@@ -62,10 +63,14 @@ public:
         std::atomic<uint64_t> barrier_count, barrier_gen;
         uint64_t gather[MAX_WORLD][GATHER_WORDS];        // scratch of the blocking helpers (between two barriers)
         Slot slots[DEPTH][MAX_WORLD];
+        // free-running progress counters of the ranks' sources (benchmark sources that read one time-ordered feed keep
+        // their synthetic clocks together across the ranks with them: bench_common.hpp SkewBound)
+        std::atomic<uint64_t> progress[MAX_WORLD][PROGRESS_LANES];
     };
     static_assert(std::atomic<uint64_t>::is_always_lock_free, "the control board needs lock-free 64-bit atomics");
 
     ControlBoard(Shared* sh, int rank, int world) : sh_(sh), rank_(rank), world_(world) {}
+    std::atomic<uint64_t>* progress(int rank) { return sh_->progress[rank]; }
 
     bool can_publish(uint64_t round) const {
         if (round < DEPTH) return true;
