@@ -712,9 +712,13 @@ private:
                 hi_ts = std::max(hi_ts, std::min(W, upper));
             }
         if (n_probe > 0) {
-            hipLaunchKernelGGL((gpu::det_count_le_kernel<tuple_t>), dim3((n_probe + gpu::BLOCK_THREADS - 1) / gpu::BLOCK_THREADS), dim3(gpu::BLOCK_THREADS), 0, s,
+            // on a stream of its own: the answer is needed on the host now, but the sorts and gathers of the previous release
+            // (stream s) need not be over for it (the packed slabs it reads are complete: host_sync above)
+            if (!det_probe_stream_) det_probe_stream_.reset(new gpu::Stream());
+            hipStream_t ps = det_probe_stream_->get();
+            hipLaunchKernelGGL((gpu::det_count_le_kernel<tuple_t>), dim3((n_probe + gpu::BLOCK_THREADS - 1) / gpu::BLOCK_THREADS), dim3(gpu::BLOCK_THREADS), 0, ps,
                                det_segs_, n_probe, W, det_counts_);
-            WF_HIP_CHECK(hipStreamSynchronize(s));
+            WF_HIP_CHECK(hipStreamSynchronize(ps));
             for (Piece& pc : pieces)
                 if (pc.probe >= 0) pc.take = det_counts_[pc.probe];
         }
@@ -886,6 +890,7 @@ private:
     bool done_ = false, finished_ = false;
     // deterministic mode
     static constexpr uint32_t DET_MAX_SEGS = 16384;
+    std::unique_ptr<gpu::Stream> det_probe_stream_;
     std::vector<std::deque<ExchangeBundle*>> det_q_;  // per producer channel, in arrival order
     std::vector<uint64_t> det_wm_;
     std::vector<bool> det_seen_, det_ended_;
