@@ -592,9 +592,9 @@ private:
         gpu::TraceRange tr("wf:ship_batch");
         if (!dev_in_pool_) {
             dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), h->capacity, cfg_.pool_slabs));
-            upload_stream_ = gpu::upload_streams() == 0
-                                 ? stream()
-                                 : gpu::shared_copy_stream(cfg_.gpu_id, 1 + (int)(this->context.getReplicaIndex() % gpu::upload_streams()));
+            // (a replica fused onto its producer is never polled between inputs: its uploads stay in its compute stream)
+            const size_t ups = this->has_input_rings() ? gpu::upload_streams(this->context.getParallelism()) : 0;
+            upload_stream_ = ups == 0 ? stream() : gpu::shared_copy_stream(cfg_.gpu_id, 1 + (int)(this->context.getReplicaIndex() % ups));
         }
         if (h->capacity > dev_in_pool_->capacity()) gpu::failwith("GPU operator: a batch larger than the first one received (producers with different batch lengths?)");
         gpu::Batch* d = dev_in_pool_->acquire(upload_stream_);

@@ -214,14 +214,18 @@ inline hipStream_t shared_copy_stream(int device, int slot = 0) {
 }
 
 // WF_UPLOAD_STREAMS=n (1..7): uploads go through n shared streams per device and the kernels are enqueued when
-// the copy is known to be complete; default 0: uploads go through each lane's compute stream
-inline size_t upload_streams() {
-    static const size_t n = [] {
+// the copy is known to be complete; 0: uploads go through each lane's compute stream.  Unset: by the operator's parallelism -
+// with many replicas the lanes' streams overlap each other's copies and kernels best (the flagship loses 10-20 % with upload
+// streams); with one or two replicas nothing else would overlap a lane's copy with its own kernels (single-key windows:
+// 0.54 -> 0.78 G tuples/s, profiles/r2_win_seq)
+inline size_t upload_streams(size_t parallelism) {
+    static const long env = [] {
         const char* e = std::getenv("WF_UPLOAD_STREAMS");
-        const long v = e ? std::atol(e) : 0;
-        return (size_t)(v < 0 ? 0 : (v > 7 ? 7 : v));
+        const long v = e ? std::atol(e) : -1;
+        return v > 7 ? 7 : v;
     }();
-    return n;
+    if (env >= 0) return (size_t)env;
+    return parallelism <= 2 ? parallelism : 0;
 }
 // WF_POOL_WAIT=device: a recycled slab's last use is waited for on the device (stream-ordered) instead of the host
 inline bool pool_wait_on_host() {

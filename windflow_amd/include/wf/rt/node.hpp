@@ -105,6 +105,8 @@ public:
     // true when the node is fed by ONE producer of its own thread (fused onto it): the two then run strictly one after the
     // other, which GPU nodes use to share the producer's stream
     bool fed_in_thread_by_one() const { return in_.empty() && n_in_ == 1; }
+    // false for a node fused onto its producers: it has no thread of its own, so nobody polls it (on_idle) between inputs
+    bool has_input_rings() const { return !in_.empty(); }
     virtual bool wants_idle() const { return false; }
     virtual void on_idle() {}
 

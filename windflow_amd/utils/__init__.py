@@ -21,7 +21,7 @@ RUNTIME_ENV = {
     "WF_LOG_DIR": "directory of the statistics dump (./log)",
     "WF_QUIET": "1: no banner on stdout (0)",
     # device side (include/wf/gpu/hip_utils.hpp, the engines)
-    "WF_UPLOAD_STREAMS": "streams the host-to-device copies of a replica alternate over",
+    "WF_UPLOAD_STREAMS": "n (1..7): host batches are uploaded through n shared streams per device, 0: through each lane's compute stream (unset: upload streams for operators with one or two replicas, compute streams otherwise)",
     "WF_D2H_STREAMS": "own: every DeviceToHost adapter copies on its own stream; shared: on the producer's",
     "WF_POOL_WAIT": "host | device: where a re-acquired slab's last use is waited for (host)",
     "WF_EDGE_WAIT": "host | device: where a consumer waits for the event of a batch produced by another stream (device)",
