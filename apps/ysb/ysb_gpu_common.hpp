@@ -63,7 +63,7 @@ struct CountWindowGPU {
 class BulkEventSource {
 public:
     BulkEventSource(const Campaigns* c, Metrics* m, uint64_t seconds, uint64_t events, uint64_t period_us)
-        : c_(c), m_(m), seconds_(seconds), events_(events), period_(period_us), n_ads_(c->n_ads()) {
+        : m_(m), seconds_(seconds), events_(events), period_(period_us), n_ads_(c->n_ads()) {
         ads_.resize(n_ads_);
         for (size_t i = 0; i < n_ads_; i++) ads_[i] = c->ad(i);
     }
@@ -98,7 +98,6 @@ public:
     }
 
 private:
-    const Campaigns* c_;
     Metrics* m_;
     uint64_t seconds_, events_, period_;
     size_t n_ads_;

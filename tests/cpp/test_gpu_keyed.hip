@@ -159,7 +159,6 @@ int main(int argc, char** argv) {
         const size_t batch = 64 * (size_t)db(rng);
         // ---- A ----------------------------------------------------------------
         {
-            SinkTotals tot;
             PipeGraph g("keyed_a", Mode::DEFAULT);
             Source src = Source_Builder(Gen(n, keys)).withParallelism(1).build();
             MultiPipe& mp = g.add_source(src);

@@ -545,12 +545,10 @@ private:
         }
         tables_->clear();
         std::vector<std::pair<gpu::Batch*, size_t>> outs;
-        size_t total = 0;
         for (size_t l = 0; l < L; l++) {
             size_t lane_total = 0;
             for (auto& pc : lane_src[l]) lane_total += pc.second;
             if (lane_total == 0 && step_out == 0) continue;
-            total += lane_total;
             size_t piece = 0, piece_off = 0, left = lane_total;
             do {
                 const size_t n = std::min(left, lane_cap_);
