@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <tuple>
@@ -111,7 +112,11 @@ struct SkewBound {
                 std::lock_guard<std::mutex> l(gate.m);
                 if (gate.stop) return;
             }
-            std::this_thread::yield();
+            // a batch takes a source ~1 ms: waiting sources sleep instead of competing with the threads they wait for
+            if (spins < 16)
+                std::this_thread::yield();
+            else
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
     void batch_done(size_t i) { mine[i].fetch_add(1, std::memory_order_release); }
