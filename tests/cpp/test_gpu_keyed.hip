@@ -451,6 +451,34 @@ int main(int argc, char** argv) {
             failures += !ok;
         }
         {
+            // the same with timestamps 2^24 apart: a release spans more than 2^32 time units, the ordered merge sorts in two rounds
+            vector<tuple_t> wide = stream;
+            for (auto& t : wide) t.ts <<= 24;
+            vector<int64_t> exp_val(wide.size());
+            {
+                map<size_t, int64_t> acc;
+                for (size_t i = 0; i < wide.size(); i++) exp_val[i] = (acc[wide[i].key] += wide[i].value);
+            }
+            PipeGraph g("keyed_i4", Mode::DETERMINISTIC);
+            auto src = BatchSource_Builder(StridedGen{&wide, 4}).withName("lanes").withParallelism(4).withBatch(batch).build_unique();
+            MultiPipe& mp = g.add_source(*src);
+            auto map = MapGPU_Builder(RunningSum()).withName("kmap").withParallelism(p2).withScratchpad(8).withMaxKeys(keys).build_unique();
+            mp.add(*map);
+            long wrong = 0, cnt = 0;
+            Sink sink = Sink_Builder([&](std::optional<tuple_t>& o) {
+                            if (o) {
+                                wrong += o->value != exp_val[o->id];
+                                cnt++;
+                            }
+                        }).withParallelism(1).build();
+            mp.add_sink(sink);
+            g.run();
+            const bool ok = (wrong == 0 && cnt == (long)n);
+            cout << "I deterministic map, wide timestamps par=" << p2 << " batch=" << batch << " wrong " << wrong << " cnt " << cnt
+                 << (ok ? "  OK" : "  FAILED") << endl;
+            failures += !ok;
+        }
+        {
             PipeGraph g("keyed_i2", Mode::DETERMINISTIC);
             auto src = BatchSource_Builder(StridedGen{&stream, 4}).withName("lanes").withParallelism(4).withBatch(batch).build_unique();
             MultiPipe& mp = g.add_source(*src);

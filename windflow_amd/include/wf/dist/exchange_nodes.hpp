@@ -185,13 +185,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS) det_count_le_kernel(const SegCo
     }
     out[i] = lo;
 }
-// sort keys of one 32-bit half of (ts - base); perm == nullptr: identity
+// The work buffer of a release holds the tuples of replica 0, then those of replica 1, ... (`off`: where each starts).
+struct DetLaneOff {
+    uint32_t off[dist::MAX_LANES + 1];
+};
+// sort keys of one 32-bit half of (ts - base); perm == nullptr: identity.  lane_shift >= 0: the replica the tuple goes to
+// is put on top of the key (bits lane_shift and up), so that ONE sort orders every replica's tuples by timestamp
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    det_keys_kernel(const T* work, uint32_t n, uint64_t base, int shift, const uint32_t* perm, uint32_t* keys, uint32_t* idx) {
+    det_keys_kernel(const T* work, uint32_t n, uint64_t base, int shift, const uint32_t* perm, uint32_t* keys, uint32_t* idx, DetLaneOff lanes,
+                    uint32_t n_lanes, int lane_shift) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t src = perm ? perm[i] : i;
-        keys[i] = (uint32_t)((((uint64_t)std::get<2>(work[src].getControlFields())) - base) >> shift);
+        uint32_t k = (uint32_t)((((uint64_t)std::get<2>(work[src].getControlFields())) - base) >> shift);
+        if (lane_shift >= 0) {
+            uint32_t l = 0;
+            while (l + 1 < n_lanes && src >= lanes.off[l + 1]) l++;
+            k |= l << lane_shift;
+        }
+        keys[i] = k;
         idx[i] = src;
     }
 }
@@ -749,50 +761,61 @@ private:
         uint64_t created = 0;  // oldest tuple of the release (latency accounting downstream)
         for (const Piece& pc : pieces)
             if (pc.take > 0 && pc.b->hdr.created_ns != 0) created = created == 0 ? pc.b->hdr.created_ns : std::min(created, pc.b->hdr.created_ns);
+        // All replicas' tuples of the release go through ONE sort: the work buffer is filled replica by replica (inside a
+        // replica: producer by producer, in arrival order) and the replica index sits on top of the sort key.
+        std::vector<size_t> lane_n(L, 0), lane_off(L + 1, 0), cursor(L, 0);
+        for (const Piece& pc : pieces) lane_n[pc.lane] += pc.take;
+        for (size_t l = 0; l < L; l++) lane_off[l + 1] = lane_off[l] + lane_n[l];
+        const size_t total = lane_off[L];
+        if (total > UINT32_MAX) gpu::failwith("Exchange_GPU: too many tuples in one deterministic release");
+        const uint32_t* perm = nullptr;
+        if (total > 0) {
+            if (det_work_.size() < total) {
+                WF_HIP_CHECK(hipStreamSynchronize(s));  // the old buffers may still be read
+                det_work_.resize(total + total / 2);
+                det_keys_.resize(total + total / 2);
+                det_idx_.resize(total + total / 2);
+            }
+            tables_->clear();
+            for (const Piece& pc : pieces) {
+                if (pc.take == 0) continue;
+                tables_->segs.push_back({pc.b->packed->template data<tuple_t>() + pc.off, det_work_.data() + lane_off[pc.lane] + cursor[pc.lane], pc.take});
+                cursor[pc.lane] += pc.take;
+            }
+            tables_->template launch<tuple_t>(s);
+            const uint32_t n32 = (uint32_t)total;
+            hipLaunchKernelGGL(gpu::det_set_u32_kernel, dim3(1), dim3(1), 0, s, det_n_dev_.data(), n32);
+            const uint64_t range = hi_ts >= base ? hi_ts - base : 0;
+            int bits = 1, lane_bits = 0;
+            while (bits < 64 && (range >> bits) != 0) bits++;
+            while ((size_t(1) << lane_bits) < L) lane_bits++;
+            gpu::DetLaneOff lo{};
+            for (size_t l = 0; l <= L; l++) lo.off[l] = (uint32_t)lane_off[l];
+            const unsigned grid = gpu::grid_for(total);
+            if (bits + lane_bits <= 32) {
+                hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 0,
+                                   (const uint32_t*)nullptr, det_keys_.data(), det_idx_.data(), lo, (uint32_t)L, lane_bits ? bits : -1);
+                perm = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), total, bits + lane_bits, s).vals;
+            } else {
+                // LSD: the low half of the timestamps, then a second stable sort on (replica, high half)
+                if (bits - 32 + lane_bits > 32) gpu::failwith("Exchange_GPU: timestamps of one deterministic release span more than 2^60");
+                hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 0,
+                                   (const uint32_t*)nullptr, det_keys_.data(), det_idx_.data(), lo, (uint32_t)L, -1);
+                auto sorted = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), total, 32, s);
+                if (det_keys2_.size() < det_keys_.size()) {
+                    det_keys2_.resize(det_keys_.size());
+                    det_idx2_.resize(det_keys_.size());
+                }
+                hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 32,
+                                   (const uint32_t*)sorted.vals, det_keys2_.data(), det_idx2_.data(), lo, (uint32_t)L, lane_bits ? bits - 32 : -1);
+                perm = det_sorter2_.sort(det_keys2_.data(), det_idx2_.data(), det_n_dev_.data(), total, bits - 32 + lane_bits, s).vals;
+            }
+        }
         for (size_t l = 0; l < L; l++) {
-            size_t n = 0;
-            for (const Piece& pc : pieces)
-                if (pc.lane == l) n += pc.take;
+            const size_t n = lane_n[l];
             // a lane that receives nothing still learns the new watermark (an empty batch): the operator behind it is a
             // producer of the next ordering point, which would otherwise wait for it for ever
             if (n == 0 && step_out == 0 && hi_ts <= base) continue;
-            if (n > UINT32_MAX) gpu::failwith("Exchange_GPU: too many tuples in one deterministic release");
-            const uint32_t* perm = nullptr;
-            if (n > 0) {
-                if (det_work_.size() < n) {
-                    WF_HIP_CHECK(hipStreamSynchronize(s));  // the old buffers may still be read
-                    det_work_.resize(n + n / 2);
-                    det_keys_.resize(n + n / 2);
-                    det_idx_.resize(n + n / 2);
-                }
-                tables_->clear();
-                size_t fill = 0;
-                for (const Piece& pc : pieces) {
-                    if (pc.lane != l || pc.take == 0) continue;
-                    tables_->segs.push_back({pc.b->packed->template data<tuple_t>() + pc.off, det_work_.data() + fill, pc.take});
-                    fill += pc.take;
-                }
-                tables_->template launch<tuple_t>(s);
-                const uint32_t n32 = (uint32_t)n;
-                hipLaunchKernelGGL(gpu::det_set_u32_kernel, dim3(1), dim3(1), 0, s, det_n_dev_.data(), n32);
-                const uint64_t range = hi_ts >= base ? hi_ts - base : 0;
-                int bits = 1;
-                while (bits < 64 && (range >> bits) != 0) bits++;
-                const unsigned grid = gpu::grid_for(n);
-                hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 0,
-                                   (const uint32_t*)nullptr, det_keys_.data(), det_idx_.data());
-                auto sorted = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), n, std::min(bits, 32), s);
-                if (bits > 32) {  // LSD: a second stable sort on the high half
-                    if (det_keys2_.size() < det_keys_.size()) {
-                        det_keys2_.resize(det_keys_.size());
-                        det_idx2_.resize(det_keys_.size());
-                    }
-                    hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 32,
-                                       (const uint32_t*)sorted.vals, det_keys2_.data(), det_idx2_.data());
-                    sorted = det_sorter2_.sort(det_keys2_.data(), det_idx2_.data(), det_n_dev_.data(), n, bits - 32, s);
-                }
-                perm = sorted.vals;
-            }
             size_t done = 0;
             do {
                 const size_t cnt = std::min(n - done, lane_cap_);
@@ -808,13 +831,13 @@ private:
                 out->host_hdr.reserved[0] = last ? step_out : 0;
                 out->host_hdr.created_ns = created;
                 out->count_on_host = true;
-                // (the header travels by value in a pinned table; the work and sort buffers are reused by the next lane in stream order)
+                // (the header travels by value in a pinned table; the work and sort buffers are reused by the next release in stream order)
                 tables_->clear();
                 tables_->hdrs.push_back(gpu::HdrWrite{out->host_hdr, out->header(), {}});
                 tables_->template launch<tuple_t>(s);
                 if (cnt > 0)
                     hipLaunchKernelGGL((gpu::det_gather_kernel<tuple_t>), dim3(gpu::grid_for(cnt)), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), perm,
-                                       out->template data<tuple_t>(), (uint32_t)done, (uint32_t)cnt);
+                                       out->template data<tuple_t>(), (uint32_t)(lane_off[l] + done), (uint32_t)cnt);
                 out->ready.record(s);
                 emit_to(out, l);
                 xstats_->lane_batches++;
