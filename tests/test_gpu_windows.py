@@ -354,11 +354,15 @@ def _fuzz_cases(n_cases, seed):
         win = slide + int(rng.integers(1, 200)) if rng.integers(0, 3) else slide * int(rng.integers(2, 9))
         n_keys = int(rng.choice([1, 2, 3, 9, 40, 300, 2500]))
         n = int(rng.integers(2000, 40000))
-        batch = int(rng.choice([257, 1000, 2048, 4096, 16384]))
+        batch = int(rng.choice([257, 1000, 2048, 4096, 16384, 32768]))
+        if n_keys <= 3 and rng.integers(0, 2):
+            n = int(rng.integers(40000, 120000))  # runs of tens of thousands of tuples: spread over the chip
         gap_every = int(rng.choice([10**9, 50, 400, 3000]))
         gap_len = int(rng.choice([3, 60, 2500]))
         disorder = int(rng.choice([0, 0, 5, 40])) if tb else 0
         delay = 0 if disorder == 0 else disorder + int(rng.integers(1, 30))
+        if tb and disorder == 0 and rng.integers(0, 5) < 2:
+            delay = int(rng.integers(1, 400))  # in order, but the windows fire late: several quanta stay open
         mode = int(rng.choice([0, 1, 2])) if not tb else 0
         cases.append((i, tb, n, n_keys, win, slide, batch, gap_every, gap_len, disorder, delay, mode))
     return cases
