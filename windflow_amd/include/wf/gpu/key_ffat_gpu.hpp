@@ -917,7 +917,9 @@ public:
                 huge_suf_.resize(huge_leaves_cap_);
             }
             WF_HIP_CHECK(hipHostMalloc((void**)&huge_seen_, 64, hipHostMallocDefault));
-            *huge_seen_ = 0;
+            // so few keys that a full batch MUST hold huge runs: the huge-run kernels are on from the first batch (otherwise the
+            // batches enqueued before the device's first report has reached the host fold their runs with one wave each)
+            *huge_seen_ = max_keys * (size_t)FFAT_HUGE_RUN <= batch_cap_ ? 1u : 0u;
         }
         // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
         // (60 KB of dynamic LDS per block of 4 waves)
