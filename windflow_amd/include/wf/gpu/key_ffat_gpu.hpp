@@ -580,32 +580,42 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             uint32_t n_late = 0;
             if (fast && g.is_tb) {
                 const uint64_t Lq = st.last_quantum;
-                uint64_t done = 0;
-                if (ok) {
-                    const uint64_t ts = cf_ts(reg);
-                    done = ts > g.delay ? (ts - g.delay) / g.pane_len : 0;
-                    if (segkey >= done + g.acc_cap) done = segkey - g.acc_cap + 1;
-                }
-                uint64_t pm = done;  // inclusive prefix maximum
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    const uint64_t o = wave_shfl_up(pm, d);
-                    if (lane >= d && o > pm) pm = o;
-                }
-                uint64_t before = wave_shfl_up(pm, 1);
-                if (lane == 0 || before < Lq) before = Lq;
-                late = ok && segkey < before;
-                const unsigned long long late_mask = __ballot(late);
-                n_late = (uint32_t)__popcll(late_mask);
-                Lq_new = wave_bcast(pm, WAVE - 1);
-                if (Lq_new < Lq) Lq_new = Lq;
-                uint64_t qm = ok && !late ? segkey : 0;  // newest quantum that received a tuple
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    const uint64_t o = wave_shfl_up(qm, d);
-                    if (lane >= d && o > qm) qm = o;
-                }
-                q_max = wave_bcast(qm, WAVE - 1);
                 const bool disorder = __ballot(ok && lane > 0 && segkey < prevkey) != 0;
-                simple = !disorder && late_mask == 0;  // the segments of the scan above are the chunk's quanta
+                const uint64_t q_first = wave_bcast(segkey, 0), q_last = wave_bcast(segkey, (int)cnt - 1);
+                auto done_of = [&](uint64_t ts, uint64_t q) {
+                    uint64_t d = ts > g.delay ? (ts - g.delay) / g.pane_len : 0;
+                    if (q >= d + g.acc_cap) d = q - g.acc_cap + 1;
+                    return d;
+                };
+                if (!disorder && q_first >= Lq) {
+                    // the common case, a chunk in timestamp order that starts at an open quantum: done_i never exceeds the
+                    // quantum of the tuple after it, so nothing is late and the last tuple alone decides what is complete
+                    const uint64_t ts_last = wave_bcast((uint64_t)cf_ts(reg), (int)cnt - 1);
+                    Lq_new = done_of(ts_last, q_last);
+                    if (Lq_new < Lq) Lq_new = Lq;
+                    q_max = q_last;
+                } else {
+                    const uint64_t done = ok ? done_of(cf_ts(reg), segkey) : 0;
+                    uint64_t pm = done;  // inclusive prefix maximum
+                    for (int d = 1; d < WAVE; d <<= 1) {
+                        const uint64_t o = wave_shfl_up(pm, d);
+                        if (lane >= d && o > pm) pm = o;
+                    }
+                    uint64_t before = wave_shfl_up(pm, 1);
+                    if (lane == 0 || before < Lq) before = Lq;
+                    late = ok && segkey < before;
+                    const unsigned long long late_mask = __ballot(late);
+                    n_late = (uint32_t)__popcll(late_mask);
+                    Lq_new = wave_bcast(pm, WAVE - 1);
+                    if (Lq_new < Lq) Lq_new = Lq;
+                    uint64_t qm = ok && !late ? segkey : 0;  // newest quantum that received a tuple
+                    for (int d = 1; d < WAVE; d <<= 1) {
+                        const uint64_t o = wave_shfl_up(qm, d);
+                        if (lane >= d && o > qm) qm = o;
+                    }
+                    q_max = wave_bcast(qm, WAVE - 1);
+                    simple = !disorder && late_mask == 0;  // the segments of the scan above are the chunk's quanta
+                }
                 fast = Lq_new - Lq <= (uint64_t)WAVE;    // (a jump in time: the sequential rules know how to skip the empty stretch)
             }
             if (fast) {
