@@ -5,6 +5,7 @@
 //
 //   test_runtime            run every case, exit 0 iff all pass
 //   test_runtime illegal N  run illegal-topology case N (must die with a WindFlow Error)
+#include "../../windflow_amd/csrc/bench_common.hpp"  // SkewBound (the benchmark sources that share keys)
 #include <atomic>
 #include <cstring>
 #include <functional>
@@ -458,8 +459,46 @@ static void test_tuple_pool() {
     CHECK(Tracked::alive.load() == 0);
 }
 
+// four "sources" of very different speed advance at most `slack` batches apart; a shutdown releases the waiters
+static void test_skew_bound() {
+    constexpr size_t N = 4;
+    constexpr uint64_t SLACK = 3, BATCHES = 400;
+    wfbench::SkewBound sb(N, SLACK);
+    wfbench::StepGate gates[N];
+    std::atomic<uint64_t> progress[N];
+    for (auto& p : progress) p = 0;
+    std::atomic<uint64_t> worst{0};
+    vector<thread> ts;
+    for (size_t i = 0; i < N; i++)
+        ts.emplace_back([&, i] {
+            for (uint64_t b = 0; b < BATCHES; b++) {
+                sb.wait_turn(i, gates[i]);
+                uint64_t slowest = UINT64_MAX;
+                for (auto& p : progress) slowest = std::min<uint64_t>(slowest, p.load());
+                const uint64_t ahead = progress[i].load() - slowest;  // (slowest may have moved on since: an upper bound is fine)
+                uint64_t w = worst.load();
+                while (ahead > w && !worst.compare_exchange_weak(w, ahead)) {}
+                if (i == 0 && b % 8 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));  // the slow one
+                progress[i]++;
+                sb.batch_done(i);
+            }
+        });
+    for (auto& t : ts) t.join();
+    for (auto& p : progress) CHECK(p.load() == BATCHES);
+    CHECK(worst.load() <= SLACK);
+    // a source blocked behind a peer that never moves again leaves when its gate shuts down
+    wfbench::SkewBound stuck(2, 1);
+    wfbench::StepGate g2[2];
+    stuck.batch_done(1);
+    thread waiter([&] { stuck.wait_turn(1, g2[1]); });
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    g2[1].shutdown();
+    waiter.join();
+}
+
 int main(int argc, char** argv) {
     if (argc == 3 && strcmp(argv[1], "illegal") == 0) return illegal(atoi(argv[2]));
+    test_skew_bound();
     test_spsc();
     test_graph();
     test_graph_blocking();

@@ -19,6 +19,13 @@
 #include <wf/basic.hpp>
 #include <wf/context.hpp>
 
+// non-temporal store (clang builtin; the host-only unit tests are built with g++, which has none: plain store there)
+#if defined(__clang__)
+#define WFBENCH_NT_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+#else
+#define WFBENCH_NT_STORE(value, ptr) (*(ptr) = (value))
+#endif
+
 namespace wfbench {
 
 // 40 bytes, same field mix as the reference benchmark tuple
@@ -28,8 +35,8 @@ struct tuple_t {
     uint64_t ts;
     double value;
     double aux;
-    __host__ __device__ std::tuple<uint64_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    __host__ __device__ void setControlFields(uint64_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE std::tuple<uint64_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(uint64_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;
@@ -43,8 +50,8 @@ struct result_t {
     uint64_t id;
     uint64_t ts;
     double value;
-    __host__ __device__ std::tuple<uint64_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    __host__ __device__ void setControlFields(uint64_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE std::tuple<uint64_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(uint64_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;
@@ -54,10 +61,10 @@ static_assert(sizeof(result_t) == 32, "benchmark result must be 32 bytes");
 
 // lift / combine of the flagship sliding-window sum
 struct LiftValue {
-    __host__ __device__ void operator()(const tuple_t& t, result_t& r) const { r.value = t.value; }
+    WF_HOST_DEVICE void operator()(const tuple_t& t, result_t& r) const { r.value = t.value; }
 };
 struct CombSum {
-    __host__ __device__ void operator()(const result_t& a, const result_t& b, result_t& out) const { out.value = a.value + b.value; }
+    WF_HOST_DEVICE void operator()(const result_t& a, const result_t& b, result_t& out) const { out.value = a.value + b.value; }
 };
 
 // A driver releases `quota` tuples per step; the source closes the step with a
@@ -259,11 +266,11 @@ public:
             if (nt) {
                 // non-temporal stores: the slab is only read back by the DMA engine; not pulling its lines into the
                 // cache first saves the read-for-ownership traffic when many ranks share the host memory system
-                __builtin_nontemporal_store(k * kmul + kadd, &buf[i].key);
-                __builtin_nontemporal_store(id, &buf[i].id);
-                __builtin_nontemporal_store(seq * tstep, &buf[i].ts);
-                __builtin_nontemporal_store((double)(seq & 1023), &buf[i].value);
-                __builtin_nontemporal_store(1.0, &buf[i].aux);
+                WFBENCH_NT_STORE(k * kmul + kadd, &buf[i].key);
+                WFBENCH_NT_STORE(id, &buf[i].id);
+                WFBENCH_NT_STORE(seq * tstep, &buf[i].ts);
+                WFBENCH_NT_STORE((double)(seq & 1023), &buf[i].value);
+                WFBENCH_NT_STORE(1.0, &buf[i].aux);
             } else {
                 buf[i].key = k * kmul + kadd;
                 buf[i].id = id;
