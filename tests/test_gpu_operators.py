@@ -61,6 +61,7 @@ SYNC_POLICIES = [
     {"WF_POOL_WAIT": "device"},
     {"WF_D2H_STREAMS": "shared", "WF_UPLOAD_STREAMS": "2"},
     {"WF_UPLOAD_STREAMS": "1", "WF_POOL_WAIT": "device", "WF_EDGE_WAIT": "host"},
+    {"WF_INHERIT_STREAMS": "0", "WF_UPLOAD_STREAMS": "0"},  # every replica on a stream of its own, uploads in the compute streams
 ]
 
 

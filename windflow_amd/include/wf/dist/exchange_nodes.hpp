@@ -798,17 +798,19 @@ private:
                 perm = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), total, bits + lane_bits, s).vals;
             } else {
                 // LSD: the low half of the timestamps, then a second stable sort on (replica, high half)
-                if (bits - 32 + lane_bits > 32) gpu::failwith("Exchange_GPU: timestamps of one deterministic release span more than 2^60");
+                const int hi_bits = bits > 32 ? bits - 32 : 0;  // (31 or 32 bits of time plus the replica index: no high half)
+                if (hi_bits + lane_bits > 32) gpu::failwith("Exchange_GPU: timestamps of one deterministic release span more than 2^60");
                 hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 0,
                                    (const uint32_t*)nullptr, det_keys_.data(), det_idx_.data(), lo, (uint32_t)L, -1);
                 auto sorted = det_sorter_.sort(det_keys_.data(), det_idx_.data(), det_n_dev_.data(), total, 32, s);
                 if (det_keys2_.size() < det_keys_.size()) {
+                    WF_HIP_CHECK(hipStreamSynchronize(s));  // the second round of an earlier release may still be reading them
                     det_keys2_.resize(det_keys_.size());
                     det_idx2_.resize(det_keys_.size());
                 }
                 hipLaunchKernelGGL((gpu::det_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, det_work_.data(), n32, base, 32,
-                                   (const uint32_t*)sorted.vals, det_keys2_.data(), det_idx2_.data(), lo, (uint32_t)L, lane_bits ? bits - 32 : -1);
-                perm = det_sorter2_.sort(det_keys2_.data(), det_idx2_.data(), det_n_dev_.data(), total, bits - 32 + lane_bits, s).vals;
+                                   (const uint32_t*)sorted.vals, det_keys2_.data(), det_idx2_.data(), lo, (uint32_t)L, lane_bits ? hi_bits : -1);
+                perm = det_sorter2_.sort(det_keys2_.data(), det_idx2_.data(), det_n_dev_.data(), total, std::max(1, hi_bits + lane_bits), s).vals;
             }
         }
         for (size_t l = 0; l < L; l++) {
