@@ -494,6 +494,36 @@ static void test_skew_bound() {
     std::this_thread::sleep_for(std::chrono::milliseconds(20));
     g2[1].shutdown();
     waiter.join();
+    // sources of three "ranks": every rank has a SkewBound of its own over the same shared rows (the control board's progress
+    // table between processes) and advances its row only; the bound holds over all ranks' sources
+    constexpr size_t RANKS = 3, PER = 2;
+    std::atomic<uint64_t> table[RANKS][PER];
+    for (auto& row : table)
+        for (auto& c : row) c = 0;
+    vector<std::unique_ptr<wfbench::SkewBound>> bounds;
+    for (size_t r = 0; r < RANKS; r++) bounds.emplace_back(new wfbench::SkewBound({table[0], table[1], table[2]}, r, PER, SLACK));
+    wfbench::StepGate g3[RANKS * PER];
+    std::atomic<uint64_t> worst3{0};
+    vector<thread> ts3;
+    for (size_t r = 0; r < RANKS; r++)
+        for (size_t i = 0; i < PER; i++)
+            ts3.emplace_back([&, r, i] {
+                for (uint64_t b = 0; b < BATCHES; b++) {
+                    bounds[r]->wait_turn(i, g3[r * PER + i]);
+                    uint64_t slowest = UINT64_MAX;
+                    for (auto& row : table)
+                        for (auto& c : row) slowest = std::min<uint64_t>(slowest, c.load());
+                    const uint64_t ahead = table[r][i].load() - slowest;
+                    uint64_t w = worst3.load();
+                    while (ahead > w && !worst3.compare_exchange_weak(w, ahead)) {}
+                    if (r == 2 && i == 1 && b % 8 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    bounds[r]->batch_done(i);
+                }
+            });
+    for (auto& t : ts3) t.join();
+    for (auto& row : table)
+        for (auto& c : row) CHECK(c.load() == BATCHES);
+    CHECK(worst3.load() < SLACK);
 }
 
 int main(int argc, char** argv) {
