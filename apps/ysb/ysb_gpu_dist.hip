@@ -9,7 +9,8 @@
 //
 //   -t rccl  (default) one PROCESS per GPU: RANK / WORLD_SIZE / LOCAL_RANK come from the launcher's environment
 //            (torchrun, mpirun wrappers, a shell loop), rank 0 hands the RCCL unique id to the others through the file
-//            given with -i (default /tmp/wf_ysb_rccl_id.<MASTER_PORT>).
+//            given with -i (default /tmp/wf_ysb_rccl_id.<MASTER_PORT>; the launcher's pid is appended, so a file a
+//            crashed job left behind is never read by the next one).
 //   -t local all ranks are threads of THIS process coupled by LocalTransport (device copies; peer copies when the
 //            ranks sit on different GPUs): the way to run the distributed query on one GPU, and the test vehicle.
 // With -x 1 the events are split on the device by ad type into two filter+join branches that are merged again in
@@ -142,7 +143,7 @@ int main(int argc, char** argv) {
     WF_HIP_CHECK(hipSetDevice(device));
     const std::string id = dist::bootstrap_id_via_file(d.id_file, rank);
     auto tr = std::make_shared<dist::RcclTransport>(rank, world, id, device);
-    if (rank == 0) std::remove(d.id_file.c_str());  // everybody has read it: the constructor ends with a barrier
+    if (rank == 0) dist::bootstrap_id_cleanup(d.id_file);  // everybody has read it: the constructor ends with a barrier
     ysb::Metrics metrics;
     ExchangeStats xs;
     metrics.start_us = current_time_usecs();

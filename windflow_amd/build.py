@@ -16,6 +16,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 
+# RCCL: compiled against the headers of the ROCm tree and linked with an RPATH to the same tree, so a native program always
+# runs with the library its headers describe.  A Python process that imported torch first already holds torch's bundled
+# librccl (same SONAME): the transports print which library answered and its version, and refuse a major-version mismatch
+# (dist/transport.hpp rccl_identity()).
+RCCL_FLAGS = ["-I/opt/rocm/include/rccl", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+
+
 def ext_path():
     return os.path.join(ROOT, "_C" + sysconfig.get_config_var("EXT_SUFFIX"))
 
@@ -50,7 +57,7 @@ def build_extension(force=False, verbose=True):
     cmd += _pybind_includes() + srcs + ["-o", out, "-lpthread"]
     rccl_inc = "/opt/rocm/include/rccl"
     if os.path.isdir(rccl_inc):
-        cmd += ["-I" + rccl_inc, "-L/opt/rocm/lib", "-lrccl"]
+        cmd += list(RCCL_FLAGS)
     if verbose:
         print("[windflow_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -70,9 +77,11 @@ def build_cpp(src, out, hip=False, extra=()):
     try:
         subprocess.check_call(cmd)
     except (subprocess.CalledProcessError, OSError):
-        # a box without the toolchain (or a read-only tree) can still run a binary that travelled with the tree
-        if os.path.exists(out):
-            print("[windflow_amd.build] could not rebuild %s, using the existing binary" % out, file=sys.stderr, flush=True)
+        # A failed rebuild must never leave a suite green on yesterday's binary.  Only a box that has no toolchain at all may
+        # opt in to running what travelled with the tree: WF_ALLOW_STALE_BINARIES=1.
+        if os.path.exists(out) and os.environ.get("WF_ALLOW_STALE_BINARIES", "0") not in ("", "0"):
+            print("[windflow_amd.build] could not rebuild %s, WF_ALLOW_STALE_BINARIES is set: using the existing binary" % out,
+                  file=sys.stderr, flush=True)
             return out
         raise
     return out
@@ -80,7 +89,7 @@ def build_cpp(src, out, hip=False, extra=()):
 
 REPO = os.path.dirname(ROOT)
 
-RCCL_FLAGS = ["-I/opt/rocm/include/rccl", "-L/opt/rocm/lib", "-lrccl"]
+
 
 # (source, binary, hip?[, extra flags]) of every native program in the tree: regression programs and applications
 PROGRAMS = [

@@ -192,7 +192,7 @@ struct KeySpace {
         quantiles = tab;
     }
     // rank drawn by 64 random bits
-    static inline uint64_t zipf_rank(const Bucket* tab, uint64_t rnd) {
+    static WF_HOST_DEVICE inline uint64_t zipf_rank(const Bucket* tab, uint64_t rnd) {
         const Bucket b = tab[rnd >> (64 - QBITS)];
         return b.span == 1 ? b.first : b.first + (uint64_t)(((rnd & 0xffffffffull) * b.span) >> 32);
     }
@@ -307,6 +307,79 @@ private:
     uint64_t opened_ns_ = 0;
     // on by default (single GPU: same throughput, lower p99 latency; several ranks: less host memory traffic); WF_BENCH_NT_STORES=0 disables
     bool nt_stores_ = std::getenv("WF_BENCH_NT_STORES") == nullptr || std::atoi(std::getenv("WF_BENCH_NT_STORES")) != 0;
+};
+
+// ---- the same stream born on the device (Device_Source) -------------------------------------------------------------
+// Generator evaluated by one GPU thread per tuple (and by the host for the watermark of a batch): a pure function of the
+// source and of the source-local sequence number, producing what GatedGenerator produces for round-robin keys and an
+// equivalent random stream for uniform / zipf keys.  With it the pipeline is fed at HBM speed: what is measured is the
+// framework and the GPU, not the PCIe link or the host's memory system (bench.py --source device).
+struct DeviceGenerator {
+    uint64_t n_keys = 1, kmul = 1, src_offset = 0, ts_step = 1;
+    int dist = KEYS_ROUNDROBIN;
+    uint32_t shared = 0;
+    const KeySpace::Bucket* q_dev = nullptr;   // zipf quantile table in device memory
+    const KeySpace::Bucket* q_host = nullptr;  // the same table on the host
+    static WF_HOST_DEVICE uint64_t mix(uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    }
+    WF_HOST_DEVICE void operator()(uint64_t seq, uint32_t replica, tuple_t& t) const {
+        const uint64_t src = (uint64_t)replica + src_offset;
+        uint64_t k, id;
+        if (dist == KEYS_ROUNDROBIN) {
+            k = seq % n_keys;
+            id = seq / n_keys;
+        } else {
+            const uint64_t rnd = mix(seq * 0x100000001B3ull + src);
+            if (dist == KEYS_UNIFORM) {
+                k = (uint64_t)(((unsigned __int128)rnd * n_keys) >> 64);
+            } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const KeySpace::Bucket* tab = q_dev;
+#else
+                const KeySpace::Bucket* tab = q_host;
+#endif
+                k = KeySpace::zipf_rank(tab, rnd);
+            }
+            id = seq;
+        }
+        t.key = shared ? k : k * kmul + src;
+        t.id = id;
+        t.ts = seq * ts_step;
+        t.value = (double)(seq & 1023);
+        t.aux = 1.0;
+    }
+};
+
+// host side of a gated device source (Device_Source::withControl): releases the driver's quota batch by batch
+struct GatedControl {
+    StepGate* gates = nullptr;
+    std::shared_ptr<SkewBound> skew;
+    bool operator()(uint64_t, uint32_t replica, size_t cap, size_t& n, uint64_t& punct) const {
+        StepGate& g = gates[replica];
+        punct = 0;
+        int64_t take = 0;
+        {
+            std::unique_lock<std::mutex> l(g.m);
+            g.cv.wait(l, [&] { return g.quota > 0 || g.stop; });
+            if (g.quota <= 0 && g.stop) {
+                n = 0;
+                return false;
+            }
+            take = g.quota < (int64_t)cap ? g.quota : (int64_t)cap;
+            g.quota -= take;
+            if (g.quota == 0) punct = g.step_id;
+        }
+        if (skew) {
+            skew->wait_turn(replica, g);
+            skew->batch_done(replica);
+        }
+        n = (size_t)take;
+        return true;
+    }
 };
 
 }  // namespace wfbench

@@ -381,18 +381,43 @@ public:
     // key, so the batches go through the device KeyBy in front of the aggregation replicas.
     WinAggPipeline(int gpu_id, size_t n_sources, size_t batch_len, size_t n_keys, uint64_t win, uint64_t slide, bool time_based, uint64_t delay,
                    size_t inflight, std::shared_ptr<dist::Transport> transport = nullptr, size_t agg_replicas = 0, int key_dist = 0,
-                   double zipf_alpha = 1.3, bool shared_keys = false, bool deterministic = false)
+                   double zipf_alpha = 1.3, bool shared_keys = false, bool deterministic = false, bool device_source = false, bool combiner = false)
         : n_sources_(n_sources), n_sinks_(n_sources), gates_(new wfbench::StepGate[n_sources]),
           graph_("win_agg_gpu", deterministic ? Mode::DETERMINISTIC : Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<SinkTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const size_t rank = transport ? (size_t)transport->rank() : 0, world = transport ? (size_t)transport->world() : 1;
-        wfbench::GatedGenerator gen(gates_.get(), wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys), 1,
-                                    n_sources, rank * n_sources, world * n_sources);
-        // sources that emit the same keys read one feed: at most 4 batches apart (bench_common.hpp SkewBound)
-        if (shared_keys) gen.bound_skew(make_skew_bound(transport, n_sources));
-        source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
-                      .withGPUConfiguration(gpu_id).build_unique();
+        wfbench::KeySpace keyspace = wfbench::KeySpace::make(n_keys, key_dist, zipf_alpha, shared_keys);
+        if (device_source) {
+            // the tuples are born in HBM (Device_Source): same stream, no host generator and no PCIe upload in the way
+            wfbench::DeviceGenerator dgen;
+            dgen.n_keys = keyspace.n_keys;
+            dgen.kmul = world * n_sources;
+            dgen.src_offset = rank * n_sources;
+            dgen.dist = key_dist;
+            dgen.shared = shared_keys ? 1u : 0u;
+            if (keyspace.quantiles) {
+                WF_HIP_CHECK(hipSetDevice(gpu_id));
+                zipf_dev_.resize(keyspace.quantiles->size());
+                WF_HIP_CHECK(hipMemcpy(zipf_dev_.data(), keyspace.quantiles->data(), keyspace.quantiles->size() * sizeof(wfbench::KeySpace::Bucket),
+                                       hipMemcpyHostToDevice));
+                zipf_host_ = keyspace.quantiles;
+                dgen.q_dev = zipf_dev_.data();
+                dgen.q_host = zipf_host_->data();
+            }
+            wfbench::GatedControl ctl;
+            ctl.gates = gates_.get();
+            if (shared_keys) ctl.skew = make_skew_bound(transport, n_sources);
+            source_ = DeviceSource_Builder(dgen).withControl(ctl).withName("device_source").withParallelism(n_sources).withBatch(batch_len)
+                          .withInFlightBatches(inflight).withGPUConfiguration(gpu_id).build_unique();
+        } else {
+            wfbench::GatedGenerator gen(gates_.get(), keyspace, 1, n_sources, rank * n_sources, world * n_sources);
+            // sources that emit the same keys read one feed: at most 4 batches apart (bench_common.hpp SkewBound)
+            if (shared_keys) gen.bound_skew(make_skew_bound(transport, n_sources));
+            source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
+                          .withGPUConfiguration(gpu_id).build_unique();
+        }
+        (void)combiner;
         MultiPipe& mp = graph_.add_source(*source_);
         KeyFFATGPUConfig wcfg;
         wcfg.win_len = win;
@@ -509,7 +534,9 @@ private:
     std::shared_ptr<SinkTotals> totals_;
     std::shared_ptr<wfbench::StepBarrier> barrier_;
     std::shared_ptr<LatencyRecorder> latency_;
-    std::unique_ptr<Batch_Source<tuple_t>> source_;
+    gpu::DeviceBuffer<wfbench::KeySpace::Bucket> zipf_dev_;
+    std::shared_ptr<std::vector<wfbench::KeySpace::Bucket>> zipf_host_;
+    std::unique_ptr<Basic_Operator> source_;
     std::unique_ptr<Exchange_GPU<tuple_t>> exchange_;
     std::unique_ptr<Key_FFAT_GPU<tuple_t, result_t>> kff_;
     std::unique_ptr<Batch_Sink<result_t>> sink_;
@@ -1082,11 +1109,11 @@ PYBIND11_MODULE(_C, m) {
           py::arg("batch_len"), py::arg("n_sources") = 1, py::arg("lanes") = 1, py::arg("max_batches_per_round") = 0);
     py::class_<WinAggPipeline>(m, "WinAggPipeline")
         .def(py::init<int, size_t, size_t, size_t, uint64_t, uint64_t, bool, uint64_t, size_t, std::shared_ptr<dist::Transport>, size_t, int, double,
-                      bool, bool>(),
+                      bool, bool, bool, bool>(),
              py::arg("gpu_id"), py::arg("n_sources"), py::arg("batch_len"), py::arg("n_keys"), py::arg("win"), py::arg("slide"),
              py::arg("time_based") = false, py::arg("delay") = 0, py::arg("inflight") = 6, py::arg("transport") = nullptr,
              py::arg("agg_replicas") = 0, py::arg("key_dist") = 0, py::arg("zipf_alpha") = 1.3, py::arg("shared_keys") = false,
-             py::arg("deterministic") = false)
+             py::arg("deterministic") = false, py::arg("device_source") = false, py::arg("combiner") = false)
         .def("step", &WinAggPipeline::step)
         .def("steps", &WinAggPipeline::steps)
         .def("close", &WinAggPipeline::close)

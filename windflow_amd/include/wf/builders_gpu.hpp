@@ -249,8 +249,14 @@ public:
         more_ = std::move(more);
         return *this;
     }
+    // the host sizes (and may punctuate) every batch: bool(seq, replica, capacity, n&, punctuation&), false = end of stream
+    DeviceSource_Builder& withControl(device_source_control_t control) {
+        control_ = std::move(control);
+        return *this;
+    }
     source_t* build_ptr() {
-        if (!more_) fatal_error("DeviceSource_Builder: withLimit() or withStopCondition() is required");
+        if (control_) return new source_t(gen_, control_, this->parallelism_, this->name_, this->cfg_.batch_len, this->cfg_.pool_slabs, this->cfg_, this->closing_);
+        if (!more_) fatal_error("DeviceSource_Builder: withLimit(), withStopCondition() or withControl() is required");
         return new source_t(gen_, more_, this->parallelism_, this->name_, this->cfg_.batch_len, this->cfg_.pool_slabs, this->cfg_, this->closing_);
     }
     std::unique_ptr<source_t> build_unique() { return std::unique_ptr<source_t>(build_ptr()); }
@@ -258,6 +264,7 @@ public:
 private:
     G gen_;
     std::function<bool(uint64_t)> more_;
+    device_source_control_t control_;
 };
 
 template <typename F>

@@ -25,8 +25,10 @@
 #pragma once
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -58,6 +60,36 @@ namespace dist {
     } while (0)
 
 // ---- RCCL -------------------------------------------------------------------------
+// Which RCCL is this process talking to?  The library is compiled against the headers of /opt/rocm and linked with an
+// RPATH to /opt/rocm/lib, so a native program runs with exactly that library.  A Python process that imported torch first
+// already holds torch's bundled librccl.so under the same SONAME and the loader hands THAT one to the extension.  Both
+// are fine for the calls used here (unique id, communicator, grouped send / recv, all-gather, all-reduce: unchanged since
+// NCCL 2.7), but the choice must be visible and a library from another major version must not be used by accident: every
+// transport reports the path and the version once, and refuses a major-version mismatch or a library older than 2.7.
+struct RcclIdentity {
+    int runtime_version = 0;                     // ncclGetVersion()
+    int header_version = NCCL_VERSION_CODE;      // what the code was compiled against
+    std::string path;                            // shared object that answered
+};
+inline const RcclIdentity& rccl_identity() {
+    static const RcclIdentity id = [] {
+        RcclIdentity r;
+        if (ncclGetVersion(&r.runtime_version) != ncclSuccess) gpu::failwith("ncclGetVersion failed");
+        Dl_info info{};
+        if (dladdr(reinterpret_cast<void*>(&ncclCommInitRank), &info) != 0 && info.dli_fname != nullptr) r.path = info.dli_fname;
+        const char* q = std::getenv("WF_QUIET");
+        if (!(q && std::atoi(q) != 0) || std::getenv("WF_RCCL_VERBOSE"))
+            std::fprintf(stderr, "[wf::dist] RCCL %d.%d.%d from %s (compiled against %d.%d.%d)\n", r.runtime_version / 10000,
+                         (r.runtime_version / 100) % 100, r.runtime_version % 100, r.path.empty() ? "?" : r.path.c_str(), r.header_version / 10000,
+                         (r.header_version / 100) % 100, r.header_version % 100);
+        if (r.runtime_version / 10000 != r.header_version / 10000 || r.runtime_version < 20700)
+            gpu::failwith("RCCL library " + r.path + " reports version " + std::to_string(r.runtime_version) + ", compiled against " +
+                          std::to_string(r.header_version) + ": refusing a library of another major version (or older than 2.7)");
+        return r;
+    }();
+    return id;
+}
+
 class RcclTransport : public Transport {
 public:
     static constexpr size_t ID_BYTES = sizeof(ncclUniqueId);
@@ -75,6 +107,7 @@ public:
         world_ = world;
         ncclUniqueId id;
         std::memcpy(&id, id_bytes.data(), sizeof(id));
+        (void)rccl_identity();  // reports the library in use, refuses an incompatible one
         WF_HIP_CHECK(hipSetDevice(device_));
         WF_RCCL_CHECK(ncclCommInitRank(&comm_, world, id, rank));
         stage_dev_.resize(STAGE_WORDS * (size_t)(world + 1));
@@ -138,8 +171,12 @@ private:
 
 // rank 0 writes the id to `path` (atomically), the others poll for it: bootstrap for
 // native programs started by a launcher that only provides RANK / WORLD_SIZE
-inline std::string bootstrap_id_via_file(const std::string& path, int rank, int timeout_s = 120) {
+inline std::string bootstrap_id_via_file(const std::string& path_prefix, int rank, int timeout_s = 120) {
+    // The ranks of one job share their parent (the launcher: torchrun's agent, a shell): its pid names the file, so a file
+    // left behind by a crashed job is never read by the next one; rank 0 also removes whatever carries the name first.
+    const std::string path = path_prefix + "." + std::to_string((long)getppid());
     if (rank == 0) {
+        (void)std::remove(path.c_str());
         const std::string id = RcclTransport::create_id();
         const std::string tmp = path + ".tmp";
         {
@@ -149,16 +186,25 @@ inline std::string bootstrap_id_via_file(const std::string& path, int rank, int 
         std::rename(tmp.c_str(), path.c_str());
         return id;
     }
+    // a stale file of the same name (pid reuse) is older than this process: skip it until rank 0 has replaced it
+    const auto started = std::chrono::system_clock::now() - std::chrono::seconds(30);
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
     while (std::chrono::steady_clock::now() < deadline) {
-        std::ifstream f(path, std::ios::binary);
-        if (f) {
-            std::string id((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-            if (id.size() == RcclTransport::ID_BYTES) return id;
+        struct stat st {};
+        if (::stat(path.c_str(), &st) == 0 && std::chrono::system_clock::from_time_t(st.st_mtime) >= started) {
+            std::ifstream f(path, std::ios::binary);
+            if (f) {
+                std::string id((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+                if (id.size() == RcclTransport::ID_BYTES) return id;
+            }
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
     gpu::failwith("bootstrap_id_via_file: timed out waiting for " + path);
+}
+// rank 0, once every rank holds its communicator: the file has done its job
+inline void bootstrap_id_cleanup(const std::string& path_prefix) {
+    (void)std::remove((path_prefix + "." + std::to_string((long)getppid())).c_str());
 }
 
 // ---- in-process fabric ---------------------------------------------------------------

@@ -314,14 +314,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 }  // namespace gpu
 
+// What the host decides for a device source, batch by batch: how many tuples the next batch holds (0 < n <= cap), whether it
+// closes a driver-defined step (punctuation, see Batch_Source) - or that the stream is over (return false).  May block
+// (a benchmark driver releasing a quota per step).
+using device_source_control_t = std::function<bool(uint64_t seq, uint32_t replica, size_t cap, size_t& n, uint64_t& punctuation)>;
+
 template <typename tuple_t, typename G>
 class Device_Source_Node : public Replica_Base {
     static_assert(std::is_trivially_copyable_v<tuple_t>, "batched tuples are raw bytes: they must be trivially copyable");
 
 public:
-    Device_Source_Node(G gen, std::function<bool(uint64_t)> more, size_t batch_len, size_t slabs, int device, std::string name, size_t par,
+    Device_Source_Node(G gen, device_source_control_t control, size_t batch_len, size_t slabs, int device, std::string name, size_t par,
                        size_t idx, meta::closing_func_t closing, std::shared_ptr<StatsHub> hub)
-        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), false, true), gen_(gen), more_(std::move(more)),
+        : Replica_Base(std::move(name), par, idx, std::move(closing), std::move(hub), false, true), gen_(gen), control_(std::move(control)),
           batch_len_(batch_len), slabs_(slabs), device_(device) {
         set_io_bytes(0, sizeof(tuple_t) * batch_len);
         gpu::preload_module(device_);
@@ -334,24 +339,34 @@ public:
         pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, device_, sizeof(tuple_t), batch_len_, slabs_));
     }
     bool generate() override {
-        if (!more_(seq_)) return false;
-        gpu::Batch* d = pool_->acquire(stream_->get());
         const uint32_t replica = (uint32_t)context.getReplicaIndex();
-        d->host_hdr.count = (uint32_t)batch_len_;
+        size_t n = 0;
+        uint64_t punct = 0;
+        if (!control_(seq_, replica, batch_len_, n, punct)) return false;
+        if (n > batch_len_) n = batch_len_;
+        if (n == 0 && punct == 0) return true;
+        gpu::Batch* d = pool_->acquire(stream_->get());
+        d->host_hdr.count = (uint32_t)n;
         d->host_hdr.source_id = replica;
         d->host_hdr.first_seq = seq_;
         d->host_hdr.created_ns = current_time_nsecs();
-        tuple_t last{};
-        gen_(seq_ + batch_len_ - 1, replica, last);  // the generator runs on the host too: the watermark is known here
-        d->host_hdr.watermark = ts_of(last);
+        d->host_hdr.reserved[0] = punct;
+        if (n > 0) {
+            tuple_t last{};
+            gen_(seq_ + n - 1, replica, last);  // the generator runs on the host too: the watermark is known here
+            d->host_hdr.watermark = ts_of(last);
+        } else {
+            d->host_hdr.watermark = last_wm_;
+        }
+        last_wm_ = d->host_hdr.watermark;
         d->count_on_host = true;
-        hipLaunchKernelGGL((gpu::device_source_kernel<tuple_t, G>), dim3(gpu::grid_for(batch_len_)), dim3(gpu::BLOCK_THREADS), 0, stream_->get(),
-                           d->header(), d->template data<tuple_t>(), seq_, (uint32_t)batch_len_, replica, d->host_hdr, gen_);
+        hipLaunchKernelGGL((gpu::device_source_kernel<tuple_t, G>), dim3(gpu::grid_for(std::max<size_t>(n, 1))), dim3(gpu::BLOCK_THREADS), 0,
+                           stream_->get(), d->header(), d->template data<tuple_t>(), seq_, (uint32_t)n, replica, d->host_hdr, gen_);
         WF_HIP_CHECK(hipGetLastError());
         d->ready.record(stream_->get());
         reaper_.tick(stream_->get());
         kernels_++;
-        seq_ += batch_len_;
+        seq_ += n;
         emit(d);
         return true;
     }
@@ -365,10 +380,10 @@ protected:
 
 private:
     G gen_;
-    std::function<bool(uint64_t)> more_;
+    device_source_control_t control_;
     size_t batch_len_, slabs_;
     int device_;
-    uint64_t seq_ = 0, kernels_ = 0;
+    uint64_t seq_ = 0, kernels_ = 0, last_wm_ = 0;
     std::unique_ptr<gpu::Stream> stream_;
     std::unique_ptr<gpu::BatchPool> pool_;
     gpu::StreamReaper reaper_;
@@ -377,16 +392,31 @@ private:
 template <typename tuple_t>
 class Device_Source : public Simple_Operator<void, tuple_t> {
 public:
+    // `more(seq)`: asked before every (full) batch with the number of tuples the replica has generated so far
     template <typename G>
     Device_Source(G gen, std::function<bool(uint64_t)> more, size_t parallelism, std::string name, size_t batch_len, size_t slabs = 6,
                   GPUConfig cfg = GPUConfig(), meta::closing_func_t closing = nullptr)
+        : Device_Source(gen, control_of(std::move(more)), parallelism, std::move(name), batch_len, slabs, cfg, std::move(closing)) {}
+    // the general form: the host sizes every batch and may punctuate it (device_source_control_t)
+    template <typename G>
+    Device_Source(G gen, device_source_control_t control, size_t parallelism, std::string name, size_t batch_len, size_t slabs = 6,
+                  GPUConfig cfg = GPUConfig(), meta::closing_func_t closing = nullptr)
         : Simple_Operator<void, tuple_t>(name, parallelism, NONE, nullptr,
                                          [=](size_t i, size_t n, std::shared_ptr<StatsHub> hub) -> rt::Node* {
-                                             return new Device_Source_Node<tuple_t, G>(gen, more, batch_len, slabs, cfg.device_for(i), name, n, i,
+                                             return new Device_Source_Node<tuple_t, G>(gen, control, batch_len, slabs, cfg.device_for(i), name, n, i,
                                                                                       closing, std::move(hub));
                                          }) {}
     edge_kind_t output_kind() const override { return EDGE_DEVICE_BATCH; }
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<tuple_t>(); }
+
+private:
+    static device_source_control_t control_of(std::function<bool(uint64_t)> more) {
+        return [more](uint64_t seq, uint32_t, size_t cap, size_t& n, uint64_t& punct) {
+            punct = 0;
+            n = cap;
+            return more(seq);
+        };
+    }
 };
 
 // ---- Batch_Sink --------------------------------------------------------------
