@@ -4,7 +4,9 @@
 // flavours side by side, on count-based sliding windows with a window sum.
 //
 //   bench_win_gpu -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide]
-//                 [-b tuples per GPU batch] [-t seconds] [-B]
+//                 [-b tuples per GPU batch] [-t seconds] [-B] [-D [-d delay]]
+// -D runs the tuple-fed graph in DEFAULT mode with TIME-based windows of the same geometry (a key ticks once per round of its
+// source; the sources are unsynchronised threads, so the windows get a triggering delay, -d, default 4 windows).
 // -B feeds the flat GPU operators (kf_gpu, wf_gpu, kff_gpu) with batches instead of tuples: Batch_Source lanes that own
 // disjoint key sets -> operator -> Batch_Sink, the stream never leaves pinned / device memory.
 #include <unistd.h>
@@ -126,12 +128,13 @@ struct TimedBatchSource {
 
 int main(int argc, char** argv) {
     std::string op = "kf_gpu";
-    bool batch_fed = false;
+    bool batch_fed = false, default_mode = false;
+    uint64_t delay = 0;
     size_t sources = 2, replicas = 4, keys = 64, batch = 4096;
     uint64_t win = 1024, slide = 128;
     double seconds = 3.0;
     int c;
-    while ((c = getopt(argc, argv, "o:s:n:k:w:l:b:t:B")) != -1) {
+    while ((c = getopt(argc, argv, "o:s:n:k:w:l:b:t:BDd:")) != -1) {
         switch (c) {
             case 'o': op = optarg; break;
             case 's': sources = std::strtoull(optarg, nullptr, 10); break;
@@ -142,6 +145,8 @@ int main(int argc, char** argv) {
             case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
             case 't': seconds = std::atof(optarg); break;
             case 'B': batch_fed = true; break;
+            case 'D': default_mode = true; break;
+            case 'd': delay = std::strtoull(optarg, nullptr, 10); break;
             default:
                 std::cout << argv[0] << " -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide] "
                           << "[-b batch] [-t seconds]" << std::endl;
@@ -191,29 +196,41 @@ int main(int argc, char** argv) {
         return 0;
     }
     const size_t keys_per_source = std::max<size_t>(1, keys);  // every source produces all the keys
-    PipeGraph graph("bench_" + op, Mode::DETERMINISTIC);  // count-based windows need ordered input
+    PipeGraph graph("bench_" + op, default_mode ? Mode::DEFAULT : Mode::DETERMINISTIC);  // count-based windows need ordered input
+    if (default_mode && delay == 0) delay = 4 * win;
+    using us = std::chrono::microseconds;
+    // time-based windows keep what the open windows (and the triggering delay) still need: every source ticks every key once per time unit
+    const size_t archive = default_mode ? (size_t)(2 * (win + delay) * sources + 2 * batch / std::max<size_t>(1, keys) + 1024) : 0;
+    auto windows = [&](auto b) {
+        if (default_mode)
+            b.withTBWindows(us(win), us(slide), us(delay));
+        else
+            b.withCBWindows(win, slide);
+        return b;
+    };
     const uint64_t t0 = current_time_usecs();
     TimedSource gen{keys_per_source, sources, t0 + (uint64_t)(seconds * 1e6), &generated};
     auto src = Source_Builder(gen).withName("source").withParallelism(sources).build_unique();
     MultiPipe& mp = graph.add_source(*src);
     std::unique_ptr<Basic_Operator> oper;
     if (op == "kf") {
-        oper = KeyFarm_Builder(sum_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
+        oper = windows(KeyFarm_Builder(sum_nic)).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kf_gpu") {
-        oper = KeyFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64).build_unique();
+        oper = windows(KeyFarmGPU_Builder(SumGPU())).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64)
+                   .withArchiveCapacity(archive).build_unique();
     } else if (op == "wf_gpu") {
-        oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64)
-                   .build_unique();
+        oper = windows(WinFarmGPU_Builder(SumGPU())).withName(op).withParallelism(replicas).withBatch(batch).withMaxKeys(keys_per_source + 64)
+                   .withArchiveCapacity(archive).build_unique();
     } else if (op == "pf_gpu") {
-        oper = PaneFarmGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas, 1).withBatch(batch)
+        oper = windows(PaneFarmGPU_Builder(SumGPU(), sum2_nic)).withName(op).withParallelism(replicas, 1).withBatch(batch)
                    .withMaxKeys(keys_per_source + 64).build_unique();
     } else if (op == "wmr_gpu") {
-        oper = WinMapReduceGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(std::max<size_t>(2, replicas), 1)
+        oper = windows(WinMapReduceGPU_Builder(SumGPU(), sum2_nic)).withName(op).withParallelism(std::max<size_t>(2, replicas), 1)
                    .withBatch(batch).withMaxKeys(keys_per_source + 64).build_unique();
     } else if (op == "kff") {
-        oper = KeyFFAT_Builder(lift_cpu, comb_cpu).withCBWindows(win, slide).withName(op).withParallelism(replicas).build_unique();
+        oper = windows(KeyFFAT_Builder(lift_cpu, comb_cpu)).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kff_gpu") {
-        oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withBatch(64 * batch)
+        oper = windows(KeyFFATGPU_Builder(LiftGPU(), CombGPU())).withName(op).withParallelism(replicas).withBatch(64 * batch)
                    .withMaxKeys(keys_per_source + 64).withOutputCapacity(1 << 18).build_unique();
     } else {
         std::cerr << "unknown operator " << op << std::endl;
@@ -227,7 +244,7 @@ int main(int argc, char** argv) {
     graph.run();
     const double elapsed = (current_time_usecs() - t0) / 1e6;
     std::cout << op << " sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source << " win=" << win << " slide=" << slide
-              << " batch=" << batch << " : " << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed
+              << " batch=" << batch << (default_mode ? " mode=DEFAULT/TB" : " mode=DETERMINISTIC/CB") << " : " << (double)generated.load() / elapsed << " tuples/s (" << (double)results.load() / elapsed
               << " windows/s), elapsed " << elapsed << " s" << std::endl;
     return 0;
 }

@@ -97,6 +97,11 @@ public:
     // node converting this operator's output one step towards tuples
     // (DEVICE_BATCH -> HOST_BATCH -> TUPLE); nullptr if the operator emits tuples
     virtual std::function<rt::Node*(edge_kind_t from)> output_adapter_factory() const { return nullptr; }
+    // Upward adaptation (tuples -> batches): an operator that works on batches and is fed by a producer of individual
+    // tuples may name a node - built per producer, FUSED onto it - that writes the producer's tuples straight into pinned
+    // host batches (gpu/batch_ops.hpp Batcher).  The operator is then wired as if a batch source fed it: no heap tuple,
+    // no queue hop and no ordering node per tuple between the CPU stage and the GPU operator.  nullptr: feed me tuples.
+    virtual std::function<rt::Node*(size_t producer, size_t n_producers)> input_batcher_factory(Mode) const { return nullptr; }
     // after a nested window operator the next operator must shuffle (A.12)
     virtual bool forces_shuffle_after() const { return false; }
     // DETERMINISTIC graphs: true if the operator itself merges the batch lanes that feed it in timestamp order (keyed GPU

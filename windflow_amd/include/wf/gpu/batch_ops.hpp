@@ -35,6 +35,9 @@ struct GPUConfig {
     size_t n_thread_block = DEFAULT_GPU_THREADS_PER_BLOCK;
     size_t pool_slabs = 6;          // slabs per pool = batches in flight (back-pressure)
     size_t scratchpad_size = 0;     // per-key (keyed map/filter) or per-thread (windows) bytes
+    // tuple producers in front of the operator fill pinned batches of batch_len tuples (Batcher); a batch that has been open
+    // for this long is shipped as it is (checked when a tuple arrives: a fused node has no timer of its own)
+    uint64_t batch_linger_us = 5000;
 };
 
 // ---- latency accounting (BASELINE.json asks for p99; the reference only has a
@@ -194,6 +197,96 @@ private:
     std::unique_ptr<gpu::BatchPool> pool_;
     std::deque<InFlight> fifo_;
 };
+
+// Batcher: adapter node in the other direction, tuples -> pinned host batches.  It is fused onto a CPU producer (Source, Map,
+// Filter, FlatMap ... replica) whose consumer is a GPU operator: the producer's tuples are written straight into the slab
+// that the GPU operator will upload - by value when the producer supports it (rt::Node::emit_value: no heap tuple at all),
+// otherwise the pooled tuple is copied and freed in the thread that created it.  What leaves the producer's thread is one
+// message per batch instead of one per tuple, and the device KeyBy / deterministic merge of the GPU operator replaces the
+// per-tuple emitters and ordering nodes of the tuple world.  (Reference: every GPU operator re-stages the tuples it receives
+// one by one, wf/win_seq_gpu.hpp:352-539, wf/map_gpu_node.hpp:249-291.)
+template <typename T>
+class Batcher : public rt::Node {
+    static_assert(std::is_trivially_copyable_v<T>, "tuples processed on the GPU travel in raw batches: they must be trivially copyable");
+
+public:
+    Batcher(size_t batch_len, size_t slabs, int device, uint64_t linger_us, size_t producer)
+        : batch_len_(std::max<size_t>(batch_len, 1)), slabs_(std::max<size_t>(slabs, 2)), device_(device), linger_ns_(linger_us * 1000),
+          producer_(producer) {
+        gpu::preload_module(device_);
+    }
+    void svc_init() override {
+        WF_HIP_CHECK(hipSetDevice(device_));
+        pool_.reset(new gpu::BatchPool(gpu::MemKind::PINNED_HOST, device_, sizeof(T), batch_len_, slabs_));
+    }
+    bool accepts_values() const override { return true; }
+    void svc_value(const void* v, int) override { append(*static_cast<const T*>(v)); }
+    void svc(void* msg, int) override {
+        T* t = static_cast<T*>(msg);
+        append(*t);
+        tuple_delete(t);
+    }
+    void flush() override { ship(); }
+
+private:
+    inline void append(const T& t) {
+        if (cur_ == nullptr) open();
+        data_[n_++] = t;
+        const uint64_t ts = ts_of(t);
+        if (ts > wm_) wm_ = ts;
+        if (n_ == batch_len_)
+            ship();
+        else if (linger_ns_ != 0 && (n_ & 63) == 0 && current_time_nsecs() - cur_->host_hdr.created_ns > linger_ns_)
+            ship();
+    }
+    void open() {
+        cur_ = pool_->acquire_host();
+        cur_->host_hdr.created_ns = current_time_nsecs();
+        data_ = cur_->template data<T>();
+        n_ = 0;
+    }
+    void ship() {
+        if (cur_ == nullptr) return;
+        if (n_ == 0) {
+            cur_->release_host();
+        } else {
+            cur_->host_hdr.count = (uint32_t)n_;
+            cur_->host_hdr.source_id = (uint32_t)producer_;
+            cur_->host_hdr.first_seq = seq_;
+            cur_->host_hdr.watermark = wm_;
+            seq_ += n_;
+            emit(cur_);
+        }
+        cur_ = nullptr;
+        n_ = 0;
+    }
+    size_t batch_len_, slabs_;
+    int device_;
+    uint64_t linger_ns_;
+    size_t producer_;
+    std::unique_ptr<gpu::BatchPool> pool_;
+    gpu::Batch* cur_ = nullptr;
+    T* data_ = nullptr;
+    size_t n_ = 0;
+    uint64_t wm_ = 0, seq_ = 0;
+};
+
+// WF_TUPLE_PATH=1: GPU operators behind CPU producers are fed tuple by tuple, as in the reference (A/B switch)
+inline bool upward_batching_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("WF_TUPLE_PATH");
+        return !(e && std::atoi(e) != 0);
+    }();
+    return on;
+}
+template <typename T>
+inline std::function<rt::Node*(size_t, size_t)> batcher_factory(const GPUConfig& cfg) {
+    if (!upward_batching_enabled()) return nullptr;
+    const size_t len = cfg.batch_len, slabs = cfg.pool_slabs;
+    const uint64_t linger = cfg.batch_linger_us;
+    const GPUConfig c = cfg;
+    return [len, slabs, linger, c](size_t i, size_t) -> rt::Node* { return new Batcher<T>(len, slabs, c.device_for(0), linger, i); };
+}
 
 // `producer_slabs` = size of the pool the device batches come from: the adapter
 // never holds more than producer_slabs - 1 of them, so the producer (which runs in

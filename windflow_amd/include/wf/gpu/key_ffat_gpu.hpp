@@ -1225,7 +1225,7 @@ public:
     Key_FFAT_GPU(L lift, C comb, KeyFFATGPUConfig wcfg, size_t parallelism, std::string name, GPUConfig cfg = GPUConfig(),
                  meta::closing_func_t closing = nullptr, routing_func_t routing = default_routing)
         : name_(std::move(name)), par_(parallelism), wcfg_(wcfg), routing_(std::move(routing)), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)),
-          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)), slabs_(cfg.pool_slabs), gpu_id_(cfg.gpu_id) {
+          counters_(std::make_shared<std::vector<gpu::FFATCounters>>(parallelism)), slabs_(cfg.pool_slabs), gpu_id_(cfg.gpu_id), cfg_(cfg) {
         if (par_ == 0) fatal_error("Key_FFAT_GPU has parallelism zero");
         auto hub = hub_;
         auto kind = kind_;
@@ -1254,6 +1254,12 @@ public:
     std::vector<gpu::FFATCounters> getDeviceCounters() const { return *counters_; }
 
     bool merges_batch_lanes_in_order() const override { return !wcfg_.lanes_are_key_disjoint; }
+    // tuple producers fill batches themselves (count-based windows keep the reference's rule: DETERMINISTIC graphs only, which
+    // the tuple path enforces)
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override {
+        if (wcfg_.lanes_are_key_disjoint || (wcfg_.type == CB && m != Mode::DETERMINISTIC)) return nullptr;
+        return batcher_factory<tuple_t>(cfg_);
+    }
     std::vector<StageSpec> build_stages(rt::Graph& g, Mode mode) override {
         StageSpec s;
         s.name = name_;
@@ -1301,6 +1307,7 @@ private:
     std::shared_ptr<std::vector<gpu::FFATCounters>> counters_;
     size_t slabs_;
     int gpu_id_;
+    GPUConfig cfg_;
     std::function<std::vector<rt::Node*>(rt::Graph&)> factory_;
 };
 

@@ -61,7 +61,7 @@ class Map_GPU : public Simple_Operator<tuple_t, result_t> {
 public:
     template <typename F>
     Map_GPU(F func, size_t parallelism, std::string name, GPUConfig cfg = GPUConfig(), meta::closing_func_t closing = nullptr)
-        : Simple_Operator<tuple_t, result_t>(name, parallelism, FORWARD, nullptr, nullptr), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)), slabs_(cfg.pool_slabs) {
+        : Simple_Operator<tuple_t, result_t>(name, parallelism, FORWARD, nullptr, nullptr), kind_(std::make_shared<edge_kind_t>(EDGE_TUPLE)), slabs_(cfg.pool_slabs), cfg_(cfg) {
         auto kind = kind_;
         this->factory_ = [func, cfg, kind, name, closing](size_t i, size_t n, std::shared_ptr<StatsHub> hub) -> rt::Node* {
             return new MapGPU_Node<tuple_t, result_t, F>(func, cfg, *kind, name, n, i, closing, std::move(hub));
@@ -72,10 +72,12 @@ public:
     bool accepts_input_kind(edge_kind_t) const override { return true; }
     void set_input_kind(edge_kind_t k) override { *kind_ = k; }
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(slabs_); }
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode) const override { return batcher_factory<tuple_t>(cfg_); }
 
 private:
     std::shared_ptr<edge_kind_t> kind_;
     size_t slabs_;
+    GPUConfig cfg_;
 };
 
 }  // namespace wf

@@ -60,6 +60,12 @@ public:
     edge_kind_t kind = EDGE_TUPLE;
     size_t slabs() const { return cfg_.pool_slabs; }
     bool key_disjoint() const { return opt_.lanes_are_key_disjoint; }
+    // tuple producers fill batches themselves (count-based windows keep the reference's rule: DETERMINISTIC graphs only, which
+    // the tuple path enforces)
+    std::function<rt::Node*(size_t, size_t)> batcher(Mode m) const {
+        if (opt_.lanes_are_key_disjoint || (type_ == CB && m != Mode::DETERMINISTIC)) return nullptr;
+        return batcher_factory<tuple_t>(cfg_);
+    }
 
     std::vector<StageSpec> build(rt::Graph& g, std::shared_ptr<StatsHub> hub_ = nullptr, bool deterministic = false) {
         StageSpec s;
@@ -140,6 +146,7 @@ public:
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, std::move(routing), opt_level) {}
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }
     edge_kind_t output_kind() const override { return flat_ ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }
     void set_input_kind(edge_kind_t k) override {
@@ -189,6 +196,7 @@ public:
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, ordered, opt_level) {}
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }
     edge_kind_t output_kind() const override { return batch_path() ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }
     void set_input_kind(edge_kind_t k) override {

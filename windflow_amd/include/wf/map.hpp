@@ -20,6 +20,13 @@ public:
             meta::invoke_rich(func_, context, *t);
             emit(t);
         } else {
+            if (this->feeds_value_consumer()) {  // the consumer copies the result (Batcher): no heap tuple for it
+                result_t r{};
+                meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t), r);
+                tuple_delete(t);
+                this->emit_value(r);
+                return;
+            }
             result_t* r = tuple_new<result_t>();
             meta::invoke_rich(func_, context, static_cast<const tuple_t&>(*t), *r);
             tuple_delete(t);

@@ -391,6 +391,23 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
     if (mode == Mode::DETERMINISTIC && tail_kind_ != EDGE_TUPLE && !op.merges_batch_lanes_in_order() &&
         (tails_.size() != op.getParallelism() || force_shuffle_ || fresh_from_split_ || op.getRoutingMode() != FORWARD))
         adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
+    // upward adaptation: a batch operator behind a producer of tuples gets a Batcher fused onto every producer (see
+    // Basic_Operator::input_batcher_factory) - unless the mode needs an order that only the tuple world's ordering nodes can
+    // give (DETERMINISTIC, lanes shuffled into an operator that does not merge its batch lanes by timestamp itself)
+    if (tail_kind_ == EDGE_TUPLE && !tails_.empty() && op.accepts_input_kind(EDGE_HOST_BATCH) &&
+        (mode != Mode::DETERMINISTIC || op.merges_batch_lanes_in_order() ||
+         (tails_.size() == op.getParallelism() && !force_shuffle_ && !fresh_from_split_ && op.getRoutingMode() == FORWARD))) {
+        if (auto make = op.input_batcher_factory(mode)) {
+            for (size_t i = 0; i < tails_.size(); i++) {
+                rt::Node* b = g.adopt(make(i, tails_.size()));
+                g.connect_fused(tails_[i].node, tails_[i].port, b);
+                tails_[i] = {b, b->add_out_port()};
+            }
+            tail_kind_ = EDGE_HOST_BATCH;
+            tail_adapter_ = nullptr;  // (the operator accepts host batches: nothing converts them back)
+            fresh_from_split_ = false;  // the batchers are the first nodes of a split branch: it now looks like any batch producer
+        }
+    }
     // edge negotiation: hand batches over when the operator can take them
     adapt_tails([&op](edge_kind_t k) { return op.accepts_input_kind(k); });
     op.set_input_kind(tail_kind_);

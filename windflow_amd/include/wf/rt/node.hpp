@@ -25,6 +25,7 @@
 
 #include "config.hpp"
 #include "spsc_queue.hpp"
+#include "tuple_pool.hpp"
 
 namespace wf {
 namespace rt {
@@ -109,6 +110,11 @@ public:
     bool has_input_rings() const { return !in_.empty(); }
     virtual bool wants_idle() const { return false; }
     virtual void on_idle() {}
+    // A node that only needs the VALUE of its input (it copies the tuple somewhere: a batch under construction) can say so;
+    // a producer fused onto it then hands it a reference to a tuple of its own (svc_value) instead of a pooled heap
+    // tuple: no allocation, no hand-over of ownership.  See emit_value() and wf::Batcher.
+    virtual bool accepts_values() const { return false; }
+    virtual void svc_value(const void* /*tuple*/, int /*channel*/) {}
 
     // ---- output ---------------------------------------------------------
     size_t add_out_port() {
@@ -142,6 +148,19 @@ public:
         }
     }
     bool has_output() const { return !out_.empty(); }
+    bool feeds_value_consumer() const { return out_.size() == 1 && out_[0].fused != nullptr && out_[0].fused->accepts_values(); }
+    // send a COPY of `t` to the next stage: by reference when the only successor is fused and takes values, as a pooled
+    // heap tuple otherwise
+    template <typename T>
+    inline void emit_value(const T& t) {
+        if (out_.size() == 1 && out_[0].fused != nullptr && out_[0].fused->accepts_values()) {
+            counters_.outputs++;
+            out_[0].fused->counters_.inputs++;
+            out_[0].fused->svc_value(&t, out_[0].fused_ch);
+        } else {
+            emit(::wf::tuple_new<T>(t));
+        }
+    }
 
     const NodeCounters& counters() const { return counters_; }
     const std::string& node_name() const { return node_name_; }

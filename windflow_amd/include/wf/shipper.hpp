@@ -15,7 +15,7 @@ public:
     explicit Shipper(rt::Node* node) : node_(node) {}
     // copy semantics
     void push(const result_t& r) {
-        node_->emit(tuple_new<result_t>(r));
+        node_->emit_value(r);  // (no heap tuple when the consumer only copies it, e.g. a Batcher in front of a GPU operator)
         delivered_++;
     }
     // move semantics

@@ -20,6 +20,13 @@ public:
         if constexpr (meta::source_sig<F>::loop) {
             return meta::invoke_rich(func_, context, shipper_);
         } else {
+            if (this->feeds_value_consumer()) {
+                // the consumer copies the tuple (a Batcher in front of a GPU operator): no heap tuple at all
+                tuple_t t{};
+                const bool more = meta::invoke_rich(func_, context, t);
+                this->emit_value(t);
+                return more;
+            }
             tuple_t* t = tuple_new<tuple_t>();
             const bool more = meta::invoke_rich(func_, context, *t);
             emit(t);
