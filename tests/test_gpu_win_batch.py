@@ -145,6 +145,38 @@ def test_time_based_out_of_order_within_delay(ext):
     check(res, ctr, oracle(t, vals, 4 * win, 4 * slide, True, 1))
 
 
+@pytest.mark.parametrize("presort", ["0", "1", "2"])
+@pytest.mark.parametrize("n_keys,lanes,lag", [(4, 4, 300), (1, 3, 2000), (50, 8, 100)])
+def test_time_based_merged_lanes_out_of_order(ext, n_keys, lanes, lag, presort, monkeypatch):
+    """The stream a replica sees behind the KeyBy of a DEFAULT graph: every batch is a concatenation of `lanes` pieces, each in
+    timestamp order, that lag each other - every run is out of order and overlaps the tuples carried from earlier batches.
+    With the (slot, timestamp) pre-sort (2: always, 1: once the device has reported disorder) runs are merged with the carry;
+    without it (0) they are repaired by the sequential fallback.  Same windows either way (newest-value function: the
+    windows must see their tuples in timestamp order)."""
+    monkeypatch.setenv("WF_TS_PRESORT", presort)
+    n, batch, win, slide = 24000, 4096, 400, 100
+    rng = np.random.default_rng(11 + n_keys)
+    per = batch // lanes
+    t = np.zeros((n, 5), dtype=np.int64)
+    vals = rng.integers(-50, 50, n).astype(np.float64)
+    clock = np.zeros(lanes, dtype=np.int64) + np.arange(lanes) * lag // max(1, lanes - 1)
+    i = 0
+    while i < n:
+        for l in range(lanes):
+            m = min(per, n - i)
+            if m <= 0:
+                break
+            t[i:i + m, 2] = (clock[l] + np.arange(m)) * lanes + l  # distinct timestamps, every lane ascending
+            clock[l] += m
+            i += m
+    t[:, 0] = rng.integers(0, n_keys, n) * 7919 + 3
+    t[:, 3] = vals.view(np.int64)
+    delay = 2 * (batch + lag * lanes)  # covers the disorder: nothing is late, windows fire all along the stream
+    res, ctr = ext.win_batch_run(t, win, slide, delay, True, max(16, n_keys), batch, 1 << 16, 1 << 16, 1)
+    assert ctr["dropped"] == 0
+    check(res, ctr, oracle(t, vals, win, slide, True, 1))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("n,n_keys,win,slide,batch", [(30000, 3, 300, 40, 4096), (40000, 500, 24, 6, 8192), (20000, 1, 1000, 100, 2048)])
 def test_wave_reduce_form_matches_oracle(ext, n, n_keys, win, slide, batch, mode):

@@ -285,10 +285,12 @@ def test_key_ffat_time_based_long_runs(ext, n, n_keys, win, slide, batch, gap_ev
     (3, 900, 20000, 10**9, 1), # ... of 2000 panes: the ring does not fit the LDS and is updated in place
     (2, 900, 500, 10**9, 1),   # ... disorder of 90 panes, most of it beyond the delay
 ])
-def test_key_ffat_time_based_bulk_path_follows_the_sequential_rules(ext, n_keys, disorder, delay, gap_every, gap_len, mode):
+def test_key_ffat_time_based_bulk_path_follows_the_sequential_rules(ext, n_keys, disorder, delay, gap_every, gap_len, mode, monkeypatch):
     """Long runs are processed 64 tuples at a time by a wave (prefix maxima of the watermark decide which tuples are late,
     ordered folds per quantum); runs shorter than 12 tuples take the tuple-at-a-time rules.  Same stream, same results,
-    same number of dropped tuples - also for combines that depend on the arrival order."""
+    same number of dropped tuples - also for combines that depend on the arrival order.  (The (key, pane) pre-sort of
+    disordered batches changes what "arrival order" means inside a batch and has a test of its own below.)"""
+    monkeypatch.setenv("WF_TS_PRESORT", "0")
     n = 24000
     t, vals = bursty_stream(n, n_keys, seed=77 + n_keys + delay, gap_every=gap_every, gap_len=gap_len, disorder=disorder)
     res_a, ctr_a = ext.key_ffat_run(t, 80, 10, delay, True, 64, 8192, 1 << 18, mode)
@@ -310,6 +312,34 @@ def test_key_ffat_time_based_bulk_path_follows_the_sequential_rules(ext, n_keys,
             done = (int(ts) - delay) // pane if ts > delay else 0
             oldest_open = max(oldest_open, done, q - ring + 1)
     assert ctr_a["dropped"] == ctr_b["dropped"] == late
+    a, b = unpack(res_a), unpack(res_b)
+    assert len(a) == len(res_a) and a.keys() == b.keys()
+    for k in a:
+        assert a[k][0] == pytest.approx(b[k][0], abs=1e-9), k
+        assert a[k][1] == b[k][1], k
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n_keys,disorder,delay", [(2, 30, 50), (2, 30, 10), (3, 40, 0), (1, 900, 500), (6, 200, 100)])
+def test_key_ffat_presort_treats_a_batch_as_arrived_in_pane_order(ext, n_keys, disorder, delay, mode, monkeypatch):
+    """Batches whose long runs are out of timestamp order are ordered by (key, pane) on the device before the engine sees them
+    (primitives.hpp TsPresorter; here forced on): same results and same late tuples as the tuple-at-a-time rules applied to
+    the stream in which every batch has been stably sorted by pane - arrival order inside a pane is kept, which the
+    order-sensitive combines (newest / oldest arrival wins) check."""
+    n, batch, win, slide = 24000, 4096, 80, 10
+    pane = math.gcd(win, slide)
+    t, vals = bursty_stream(n, n_keys, seed=501 + n_keys + delay, gap_every=10**9, gap_len=1, disorder=disorder)
+    monkeypatch.setenv("WF_TS_PRESORT", "2")
+    res_a, ctr_a = ext.key_ffat_run(t, win, slide, delay, True, 64, batch, 1 << 18, mode)
+    # the reference stream: each batch sorted by pane (stable), fed tuple by tuple without any pre-sort
+    t_ref = t.copy()
+    for off in range(0, n, batch):
+        blk = t_ref[off:off + batch]
+        t_ref[off:off + batch] = blk[np.argsort(blk[:, 2] // pane, kind="stable")]
+    monkeypatch.setenv("WF_TS_PRESORT", "0")
+    res_b, ctr_b = ext.key_ffat_run(t_ref, win, slide, delay, True, 64, 8 * n_keys, 1 << 18, mode)
+    assert ctr_a["overflow"] == 0 and ctr_b["overflow"] == 0
+    assert ctr_a["dropped"] == ctr_b["dropped"]
     a, b = unpack(res_a), unpack(res_b)
     assert len(a) == len(res_a) and a.keys() == b.keys()
     for k in a:
@@ -494,8 +524,10 @@ def test_key_ffat_huge_runs_time_based_with_triggering_delay(ext, win, slide, de
         assert got[k][0] == pytest.approx(s, abs=1e-9), k
 
 
-def test_key_ffat_huge_runs_with_disorder_fall_back(ext):
-    """a hot key whose tuples are not in timestamp order (delay 0: the late ones are dropped, by the same rules as a short run)"""
+def test_key_ffat_huge_runs_with_disorder_fall_back(ext, monkeypatch):
+    """a hot key whose tuples are not in timestamp order (delay 0: the late ones are dropped, by the same rules as a short run;
+    without the (key, pane) pre-sort, which would make the tuples of a batch arrive in order)"""
+    monkeypatch.setenv("WF_TS_PRESORT", "0")
     t, vals = hot_stream(80_000, 20, 0.7, seed=17)
     rng = np.random.default_rng(3)
     t[:, 2] = np.maximum(0, t[:, 2] + rng.integers(-400, 1, len(t)))

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             // late tuples, disorder across the run, or a run that is sparse in time (more panes than tuples: most windows are
             // empty): the sequential rules handle them
             if (q0 < hr.Lq || q1 < q0 || q1 - hr.Lq > (uint64_t)hr.len + WAVE + g.acc_cap) {
-                hr.fallback = 1;
+                hr.fallback = q1 < q0 ? 3 : 1;  // bit 1: out of timestamp order (reported to the host, which then pre-sorts the batches)
             } else {
                 hr.max_panes = (uint32_t)(q1 - hr.Lq) + 1;
                 // the run is in timestamp order (the chunks check it): its last tuple decides what is complete afterwards
@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             if (lane == 0 && pos > 0 && ok) prev = cf_ts(data[sidx[hr.head + pos - 1]]) / pane_len - hr.Lq;
             const bool bad = ok && ((pos > 0 && pane < prev) || pane >= (uint64_t)hr.max_panes);
             if (__ballot(bad) != 0) {
-                if (lane == 0) atomicOr(&runs[lo].fallback, 1u);
+                const bool disorder = __ballot(ok && pos > 0 && pane < prev) != 0;
+                if (lane == 0) atomicOr(&runs[lo].fallback, disorder ? 3u : 1u);
                 continue;
             }
         }
@@ -339,7 +340,8 @@ template <typename R, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
                          const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint8_t* leaf_has, uint32_t* out_count, uint32_t* long_heads,
-                         uint32_t* n_long, const unsigned long long* table, FFATCounters* ctr, C comb) {
+                         uint32_t* n_long, const unsigned long long* table, FFATCounters* ctr, C comb, volatile uint32_t* disorder_seen = nullptr,
+                         uint32_t batch_no = 0) {
     const uint32_t nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -347,7 +349,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < nr; r += waves_total) {
         FFATHugeRun hr = runs[r];
         if (hr.fallback) {
-            if (lane == 0) long_heads[atomicAdd(n_long, 1u)] = hr.head;
+            if (lane == 0) {
+                long_heads[atomicAdd(n_long, 1u)] = hr.head;
+                if ((hr.fallback & 2u) && disorder_seen != nullptr) *disorder_seen = batch_no;
+            }
             continue;
         }
         FFATKeyState<R> st = states[hr.slot];

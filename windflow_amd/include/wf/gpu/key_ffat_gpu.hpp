@@ -435,7 +435,8 @@ template <bool GBULK, typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
                             R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
-                            const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb) {
+                            const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb,
+                            volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0) {
     extern __shared__ __align__(16) char ffat_smem[];
     const uint32_t n = hdr->count;
     const uint32_t runs = *n_long;
@@ -581,6 +582,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             if (fast && g.is_tb) {
                 const uint64_t Lq = st.last_quantum;
                 const bool disorder = __ballot(ok && lane > 0 && segkey < prevkey) != 0;
+                // (the host then orders the following batches by (key, timestamp) before they get here: primitives.hpp TsPresorter)
+                if (disorder && lane == 0 && disorder_seen != nullptr) *disorder_seen = batch_no;
                 const uint64_t q_first = wave_bcast(segkey, 0), q_last = wave_bcast(segkey, (int)cnt - 1);
                 auto done_of = [&](uint64_t ts, uint64_t q) {
                     uint64_t d = ts > g.delay ? (ts - g.delay) / g.pane_len : 0;
@@ -911,10 +914,16 @@ public:
         n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
         WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
         // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones whose ring of open quanta is not enormous
-        huge_ok_ = (!g_.is_tb || g_.acc_cap <= 8192) && env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
+        // (a long triggering delay keeps many quanta open: the scratch of a run spans all of them.  Sized for the 288 GB of an
+        // MI355X: up to 2^18 open quanta per key as long as the scratch stays below 6 GB; beyond that the wave-per-run kernel)
+        huge_ok_ = env_flag("WF_FFAT_HUGE", true) && batch_cap_ >= FFAT_HUGE_RUN;
         if (huge_ok_) {
             huge_max_runs_ = (uint32_t)(batch_cap_ / FFAT_HUGE_RUN + 1);
-            huge_leaves_cap_ = (uint32_t)(batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70 + (g_.is_tb ? g_.acc_cap : 0)));
+            const size_t leaves = batch_cap_ + (size_t)huge_max_runs_ * (g_.win_panes + 70 + (g_.is_tb ? g_.acc_cap : 0));
+            if (g_.is_tb && (g_.acc_cap > (1u << 18) || leaves * (3 * sizeof(R) + 1) > (6ull << 30) || leaves >= (1ull << 31))) huge_ok_ = false;
+            huge_leaves_cap_ = (uint32_t)leaves;
+        }
+        if (huge_ok_) {
             huge_heads_.resize(huge_max_runs_);
             huge_runs_.resize(huge_max_runs_);
             huge_ctl_.resize(1);
@@ -991,6 +1000,7 @@ public:
         return out;
     }
     uint64_t graph_launches() const { return graph_launches_; }
+    uint64_t presorted_batches() const { return presorted_batches_; }
 
 private:
     void enqueue(Batch* in, Batch* out, size_t upper, hipStream_t s) {
@@ -1001,10 +1011,17 @@ private:
             hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
                                out->header(), (uint32_t*)nullptr);
-            const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+            // time-based windows fed by merged, unsynchronised lanes: runs out of timestamp order are folded sequentially by the
+            // kernels below; once they report such runs the batches are ordered by (slot, timestamp) first, so that the parallel
+            // in-order paths (bulk, huge runs) apply
+            batch_no_++;
+            const bool presort = g_.is_tb && !use_graphs_ && disorder_.decide(batch_no_);
+            const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1,
+                                                         disorder_.ts_bits(), g_.pane_len, disorder_.clamped(), batch_no_, s)
+                                        : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+            if (presort) presorted_batches_++;
             // huge runs: the four extra launches are only made while the stream shows such runs (the short-run kernel reports
             // them through a pinned word; a run that shows up while they are off is handled by the wave-per-run kernel)
-            batch_no_++;
             uint32_t huge_mode = 0;
             if (huge_ok_ && !use_graphs_) {
                 const uint32_t seen = *huge_seen_;
@@ -1028,7 +1045,8 @@ private:
                 const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
                                    acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
-                                   huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_);
+                                   huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_,
+                                   disorder_.seen(), batch_no_);
                 const bool hgw = g_.win_panes > FFAT_HUGE_DIRECT_WIN;
                 if (hgw) {
                     // two work items per block of win_panes leaves, a wave each
@@ -1047,12 +1065,12 @@ private:
                 hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
             else
                 hipLaunchKernelGGL((ffat_update_long_kernel<false, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
         }
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
                            n_long_.data() + 1);
@@ -1134,6 +1152,9 @@ private:
     }
     size_t long_lds_bytes_ = 0;
     RadixSorter sorter_;
+    TsPresorter presorter_;
+    DisorderMonitor disorder_;
+    uint64_t presorted_batches_ = 0;
     std::unique_ptr<BatchPool> out_pool_;
 };
 

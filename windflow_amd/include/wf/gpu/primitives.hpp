@@ -17,7 +17,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <tuple>
 
 #include "hip_utils.hpp"
 #include "kernels_basic.hpp"
@@ -531,6 +534,131 @@ public:
 private:
     size_t cap_ = 0, tiles_ = 0;
     DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_, bin_totals_;
+};
+
+// ---------------------------------------------------------------------------
+// (slot, timestamp) order for batches whose keys arrive OUT of timestamp order
+// ---------------------------------------------------------------------------
+// The keyed engines give every key a contiguous run in ARRIVAL order (stable sort by slot).  A batch that merges several
+// unsynchronised lanes (the device KeyBy of a DEFAULT graph, an exchange round) is a concatenation of sorted pieces: every
+// run is out of timestamp order, and the per-run repairs (an insertion sort in the non-incremental engine, a sequential
+// fold in the incremental one) are quadratic / serial in the run length.  Instead the whole batch is ordered by
+// (slot, timestamp) with two stable radix sorts - by the low bits of (ts - base), then by slot - after which every run is in
+// timestamp order and the engines' parallel in-order paths apply.  Time is counted in `unit`s (1: timestamps; the pane length:
+// the tuples of a pane keep their arrival order, which is what an order-sensitive combine folds them in); `bits` of it are
+// sorted (base = batch watermark - (2^bits - 1)); tuples outside that span are clamped and reported (the engines then fall
+// back to their repairs for the affected runs, and the caller widens the span).  Ties keep their arrival order.
+// Semantics: the tuples of ONE batch are then treated as if they had arrived in (unit-granular) timestamp order, so none of
+// them is late with respect to another tuple of the same batch; lateness against earlier batches follows the usual rules.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ts_keys_kernel(const BatchHeader* hdr, const T* data, uint32_t bits, uint64_t unit, uint32_t* keys, uint32_t* idx, volatile uint32_t* clamp_seen,
+                   uint32_t batch_no) {
+    const uint32_t n = hdr->count;
+    const uint64_t wm = hdr->watermark / unit;
+    const uint64_t span = bits >= 32 ? 0xffffffffull : ((1ull << bits) - 1ull);
+    const uint64_t base = wm > span ? wm - span : 0ull;
+    bool clamped = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t ts = (uint64_t)std::get<2>(data[i].getControlFields()) / unit;
+        uint64_t k = ts > base ? ts - base : 0ull;
+        if (ts < base || k > span) clamped = true;
+        if (k > span) k = span;
+        keys[i] = (uint32_t)k;
+        idx[i] = i;
+    }
+    if (__ballot(clamped) != 0 && lane_id() == 0 && clamp_seen != nullptr) *clamp_seen = batch_no;
+}
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    gather_u32_kernel(const BatchHeader* hdr, const uint32_t* src, const uint32_t* perm, uint32_t* dst) {
+    const uint32_t n = hdr->count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[perm[i]];
+}
+
+class TsPresorter {
+public:
+    void reserve(size_t capacity) {
+        if (capacity <= cap_) return;
+        cap_ = capacity;
+        keys_.resize(capacity);
+        idx_.resize(capacity);
+        slot2_.resize(capacity);
+        by_ts_.reserve(capacity);
+        by_slot_.reserve(capacity);
+    }
+    // `slot[i]` = slot of tuple i (arrival order).  Returns (sorted slots, permutation): position p of the result holds tuple
+    // perm[p]; slots ascending, timestamps ascending inside a slot (as far as `bits` of time reach).
+    template <typename T>
+    RadixSorter::Sorted sort(const BatchHeader* hdr, const T* data, const uint32_t* n_dev, size_t n_upper, const uint32_t* slot, int slot_bits, int ts_bits,
+                             uint64_t unit, volatile uint32_t* clamp_seen, uint32_t batch_no, hipStream_t s) {
+        reserve(n_upper);
+        const unsigned grid = grid_for(std::max<size_t>(n_upper, 1));
+        hipLaunchKernelGGL((ts_keys_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, hdr, data, (uint32_t)ts_bits, unit ? unit : 1, keys_.data(), idx_.data(),
+                           clamp_seen, batch_no);
+        const auto by_ts = by_ts_.sort(keys_.data(), idx_.data(), n_dev, n_upper, ts_bits, s);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid), dim3(BLOCK_THREADS), 0, s, hdr, slot, by_ts.vals, slot2_.data());
+        return by_slot_.sort(slot2_.data(), by_ts.vals, n_dev, n_upper, slot_bits, s);
+    }
+    int kernels(int slot_bits, int ts_bits) const { return 2 + by_ts_.kernels_per_sort(ts_bits) + by_slot_.kernels_per_sort(slot_bits); }
+
+private:
+    size_t cap_ = 0;
+    DeviceBuffer<uint32_t> keys_, idx_, slot2_;
+    RadixSorter by_ts_, by_slot_;
+};
+
+// When to pre-sort: a pinned word the engine's kernels write the batch number to whenever they meet a run that is out of
+// timestamp order (`seen`), another one for clamped timestamps (`clamped`).  The pre-sort stays on while disorder keeps
+// showing; it is switched off for ONE probing batch after `linger` quiet batches (the pre-sort hides the disorder it cures),
+// and every time the probe finds disorder again the next linger doubles.
+class DisorderMonitor {
+public:
+    DisorderMonitor() {
+        WF_HIP_CHECK(hipHostMalloc((void**)&words_, 64, hipHostMallocDefault));
+        words_[0] = words_[1] = 0;
+        if (const char* e = std::getenv("WF_TS_PRESORT")) mode_ = std::atoi(e);  // 0: never, 1: adaptive (default), 2: always
+    }
+    ~DisorderMonitor() {
+        if (words_) (void)hipHostFree((void*)words_);
+    }
+    DisorderMonitor(const DisorderMonitor&) = delete;
+    DisorderMonitor& operator=(const DisorderMonitor&) = delete;
+    volatile uint32_t* seen() const { return words_; }
+    volatile uint32_t* clamped() const { return words_ + 1; }
+    // called once per batch, before its kernels are enqueued: pre-sort this batch?
+    // sticky: once disorder has been seen the pre-sort stays on (engines whose repair of an unsorted run is quadratic)
+    void set_sticky(bool b) { sticky_ = b; }
+    // the caller knows its input is a merge of unsynchronised lanes: pre-sort from the first batch on
+    void expect_disorder() {
+        if (mode_ == 1) mode_ = 2;
+    }
+    bool decide(uint32_t batch_no) {
+        if (mode_ == 0) return false;
+        if (mode_ == 2) return true;
+        if (sticky_ && on_since_ != 0) return true;
+        const uint32_t seen = words_[0];
+        if (seen != 0 && seen != last_seen_) {  // a new report
+            if (on_since_ != 0 && probing_) linger_ = std::min<uint32_t>(linger_ * 2, 1u << 20);
+            last_seen_ = seen;
+            quiet_from_ = batch_no;
+            if (on_since_ == 0) on_since_ = batch_no;
+            probing_ = false;
+        }
+        if (on_since_ == 0) return false;
+        if (batch_no - quiet_from_ > linger_) {  // quiet for long: let one batch through unsorted and see
+            probing_ = true;
+            quiet_from_ = batch_no;
+            return false;
+        }
+        return true;
+    }
+    int ts_bits() const { return words_[1] != 0 ? 32 : 22; }
+
+private:
+    volatile uint32_t* words_ = nullptr;
+    int mode_ = 1;
+    uint32_t last_seen_ = 0, quiet_from_ = 0, on_since_ = 0, linger_ = 1024;
+    bool probing_ = false, sticky_ = false;
 };
 
 }  // namespace gpu

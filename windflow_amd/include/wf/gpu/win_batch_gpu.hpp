@@ -180,11 +180,21 @@ constexpr uint32_t WB_NO_RUN = 0xffffffffu;  // WinKeyState::cur_run of a key wh
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     wb_runs_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const unsigned long long* table,
-                   WinKeyState* states, WinRun* runs, uint32_t* work_len, T* carry, WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t quiet_ok) {
+                   WinKeyState* states, WinRun* runs, uint32_t* work_len, T* carry, WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t quiet_ok,
+                   uint32_t* unsorted_stamp, uint32_t batch_no, volatile uint32_t* disorder_seen) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
-        if (i > 0 && sslot[i - 1] == slot) continue;  // not the head of a run
+        if (i > 0 && sslot[i - 1] == slot) {  // not the head of a run
+            // is the run in ordinal order?  (Runs that are get their tuples MERGED with the carried ones by the gather; the
+            // others are placed in arrival order and repaired by wb_sortfix_kernel - and reported, so that the host orders
+            // the following batches by (slot, timestamp) before they get here.)
+            if (!g.renumber && slot != 0xffffffffu && win_ord(data[sidx[i - 1]], g.is_tb) > win_ord(data[sidx[i]], g.is_tb)) {
+                unsorted_stamp[slot] = batch_no;
+                if (disorder_seen != nullptr && i + 32 < n && sslot[i + 32] == slot) *disorder_seen = batch_no;  // (short runs are cheap to repair)
+            }
+            continue;
+        }
         // end of the run: gallop, then bisect (sslot is sorted)
         uint32_t lo = i, step = 1;
         while (lo + step < n && sslot[lo + step] == slot) {
@@ -270,20 +280,48 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 
 // ---- 4. segments = carried tuples + run --------------------------------------------------------
+// number of elements of the sorted sequence seq[0..n) (read through `at`) whose ordinal is < x (strict) / <= x
+template <typename At>
+__device__ __forceinline__ uint32_t wb_count_below(At at, uint32_t n, uint64_t x, bool or_equal) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t o = at(mid);
+        if (o < x || (or_equal && o == x))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     wb_gather_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const WinKeyState* states, WinRun* runs,
-                     const uint32_t* work_off, const T* carry, T* work, const WinCtl* ctl, WinCounters* ctr, WinGeometry g) {
+                     const uint32_t* work_off, const T* carry, T* work, const WinCtl* ctl, WinCounters* ctr, WinGeometry g,
+                     const uint32_t* unsorted_stamp, uint32_t batch_no) {
     const uint32_t n = hdr->count;
     const uint32_t n_runs = ctl->n_runs;
+    // A run that is in ordinal order (the common case; always after the (slot, timestamp) pre-sort) is MERGED with the carried
+    // tuples of its key, which are in order too: the position of every tuple in the segment is its own index plus the number
+    // of tuples of the other sequence that go before it (carried tuples first on ties) - one comparison when the run begins
+    // after the last carried tuple, a binary search in the overlap otherwise.  No thread moves more than one tuple.
     // (a) the carried tuples, one wave per run
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < n_runs; r += waves_total) {
-        const uint32_t off = work_off[r], clen = runs[r].carry_len;
+        const uint32_t off = work_off[r], clen = runs[r].carry_len, start = runs[r].start, len = runs[r].len;
         if (lane_id() == 0) runs[r].seg_off = off;
         const T* src = carry + (size_t)runs[r].dense * g.carry_cap;
-        for (uint32_t k = lane_id(); k < clen; k += WAVE)
-            if (off + k < g.work_cap) work[off + k] = src[k];
+        const bool merge = !g.renumber && len > 0 && clen > 0 && unsorted_stamp[runs[r].slot] != batch_no;
+        const uint64_t r_first = merge ? win_ord(data[sidx[start]], g.is_tb) : 0;
+        for (uint32_t k = lane_id(); k < clen; k += WAVE) {
+            uint32_t before = 0;
+            if (merge) {
+                const uint64_t o = win_ord(src[k], g.is_tb);
+                if (o > r_first) before = wb_count_below([&](uint32_t m) { return win_ord(data[sidx[start + m]], g.is_tb); }, len, o, false);
+            }
+            if (off + k + before < g.work_cap) work[off + k + before] = src[k];
+        }
     }
     // (b) the tuples of the batch, one thread per tuple
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -294,31 +332,26 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint32_t r = st->cur_run;
         if (r == WB_NO_RUN) continue;  // appended to the key's carry area by wb_runs_kernel
         const uint32_t start = runs[r].start, clen = runs[r].carry_len;
-        const uint32_t dst = work_off[r] + clen + (j - start);
-        if (dst >= g.work_cap) {
-            atomicAdd(&ctr->work_overflow, 1u);
-            continue;
-        }
         T t = data[sidx[j]];
         uint64_t ord;
+        uint32_t dst = work_off[r] + clen + (j - start);
         if (g.renumber) {
             ord = runs[r].base_count + (uint64_t)(j - start);
             t.setControlFields(cf_key(t), ord, cf_ts(t));
         } else {
             ord = win_ord(t, g.is_tb);
-            // order inside the segment: against the previous tuple of the run, or the last carried one
-            uint64_t prev = 0;
-            bool has_prev = false;
-            if (j > start) {
-                prev = win_ord(data[sidx[j - 1]], g.is_tb);
-                has_prev = true;
-            } else if (clen > 0) {
-                prev = win_ord(carry[(size_t)runs[r].dense * g.carry_cap + clen - 1], g.is_tb);
-                has_prev = true;
-            }
-            if (has_prev && prev > ord) {
+            const T* area = carry + (size_t)runs[r].dense * g.carry_cap;
+            if (unsorted_stamp[slot] != batch_no) {
+                // merge position: the carried tuples whose ordinal is <= mine go before me
+                if (clen > 0) {
+                    uint32_t before = clen;
+                    if (ord < win_ord(area[clen - 1], g.is_tb)) before = wb_count_below([&](uint32_t m) { return win_ord(area[m], g.is_tb); }, clen, ord, true);
+                    dst = work_off[r] + before + (j - start);
+                }
+            } else {
+                // arrival order, repaired afterwards (wb_sortfix_kernel); the greatest ordinal can be anywhere in the run
                 runs[r].unsorted = 1;
-                if (j > start) atomicMax((unsigned long long*)&runs[r].max_ord, (unsigned long long)prev);  // a local maximum
+                atomicMax((unsigned long long*)&runs[r].max_ord, (unsigned long long)ord);
             }
             // late: older than every window still open (tuples in the gaps between hopping windows are not late, just unused)
             if (ord < runs[r].keep_from && runs[r].first_lwid > 0 &&
@@ -326,6 +359,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 atomicAdd(&ctr->dropped, 1u);
         }
         if (j == start + runs[r].len - 1) atomicMax((unsigned long long*)&runs[r].max_ord, (unsigned long long)ord);
+        if (dst >= g.work_cap) {
+            atomicAdd(&ctr->work_overflow, 1u);
+            continue;
+        }
         work[dst] = t;
     }
 }
@@ -735,6 +772,7 @@ struct WinGPUOptions {
     size_t out_capacity = 0;      // results per output batch (0: twice the input batch capacity)
     bool renumber = false;        // count-based windows: count arrivals per key on the device instead of trusting the ids
     bool lanes_are_key_disjoint = false;  // batch input: lane i already carries exactly the keys of replica i
+    bool expect_disorder = false;  // the input merges unsynchronised lanes (DEFAULT graph): order every batch by (key, timestamp) first
 };
 
 // The engine proper: owns the device state, turns device batches of tuples into device batches of results.
@@ -789,6 +827,10 @@ public:
         WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_.bytes(), init.get()));
         states_.resize(table_cap_);
         WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, states_.bytes(), init.get()));
+        unsorted_stamp_.resize(table_cap_);
+        WF_HIP_CHECK(hipMemsetAsync(unsorted_stamp_.data(), 0, unsorted_stamp_.bytes(), init.get()));
+        disorder_.set_sticky(true);  // (the repair of an unsorted run is a sequential insertion sort: never go back to it)
+        if (opt.expect_disorder) disorder_.expect_disorder();
         carry_.resize((size_t)g_.max_keys * g_.carry_cap);
         work_.resize(work);
         slot_.resize(batch_cap_);
@@ -830,6 +872,7 @@ public:
     WinBatchEngine& operator=(const WinBatchEngine&) = delete;
 
     const WinGeometry& geometry() const { return g_; }
+    uint64_t presorted_batches() const { return presorted_batches_; }
     size_t device_bytes() const { return table_.bytes() + states_.bytes() + carry_.bytes() + work_.bytes(); }
 
     // enqueue the processing of `in` on `s`; returns the batch of fired windows (count on the device)
@@ -853,13 +896,22 @@ public:
         hipLaunchKernelGGL((assign_slots_kernel<T, KeyFn>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.data(),
                            (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyFn{}, out->header(),
                            &ctl_.data()->n_runs);
-        const auto sorted = sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+        // ordinals that are not assigned here (timestamps, user ids) may arrive out of order: once the device has reported runs
+        // that are, or when the caller knows its input is a merge of unsynchronised lanes, the batch is ordered by (slot,
+        // timestamp) instead of (slot, arrival)
+        batch_no_++;
+        const bool presort = g_.is_tb && !g_.renumber && disorder_.decide(batch_no_);
+        const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1, 32,
+                                                     1, disorder_.clamped(), batch_no_, s)
+                                    : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+        if (presort) presorted_batches_++;
         hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
                            table_.data(), states_.data(), runs_.data(), work_len_.data(), carry_.data(), ctl_.data(), counters_.data(), g_,
-                           quiet_runs_ ? 1u : 0u);
+                           quiet_runs_ ? 1u : 0u, unsorted_stamp_.data(), batch_no_, disorder_.seen());
         exclusive_scan_u32(work_len_.data(), work_off_.data(), runs_upper, &ctl_.data()->work_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
         hipLaunchKernelGGL((wb_gather_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
-                           states_.data(), runs_.data(), work_off_.data(), carry_.data(), work_.data(), ctl_.data(), counters_.data(), g_);
+                           states_.data(), runs_.data(), work_off_.data(), carry_.data(), work_.data(), ctl_.data(), counters_.data(), g_,
+                           unsorted_stamp_.data(), batch_no_);
         if (!g_.renumber)
             hipLaunchKernelGGL((wb_sortfix_kernel<T>), dim3(rgrid), dim3(BLOCK_THREADS), 0, s, runs_.data(), work_.data(), ctl_.data(), g_);
         hipLaunchKernelGGL(wb_plan_kernel, dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), runs_.data(), n_fire_.data(), ctl_.data(), g_);
@@ -954,7 +1006,11 @@ private:
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<WinKeyState> states_;
     DeviceBuffer<T> carry_, work_;
-    DeviceBuffer<uint32_t> slot_, idx_, work_len_, work_off_, n_fire_, win_off_;
+    DeviceBuffer<uint32_t> slot_, idx_, work_len_, work_off_, n_fire_, win_off_, unsorted_stamp_;
+    TsPresorter presorter_;
+    DisorderMonitor disorder_;
+    uint32_t batch_no_ = 0;
+    uint64_t presorted_batches_ = 0;
     DeviceBuffer<WinRun> runs_;
     DeviceBuffer<WinDesc> desc_;
     DeviceBuffer<unsigned long long> scan_ws_;

@@ -81,6 +81,8 @@ public:
         gpu::WinGPUOptions opt = opt_;
         // batches carry no per-key renumbering stage in front of them: count-based windows count arrivals on the device
         if (kind != EDGE_TUPLE && type_ == CB) opt.renumber = true;
+        // time-based windows behind several unsynchronised producers (DEFAULT graph): every replica sees a merge of sorted pieces
+        if (type_ == TB && !deterministic && !opt.lanes_are_key_disjoint) opt.expect_disorder = true;
         const bool keyby = kind != EDGE_TUPLE && !opt.lanes_are_key_disjoint && (N > 1 || deterministic);
         const edge_kind_t node_kind = keyby ? EDGE_DEVICE_BATCH : kind;
         for (size_t i = 0; i < N; i++) s.replicas.push_back(g.adopt(factory_(p, opt, node_kind, N, i)));
