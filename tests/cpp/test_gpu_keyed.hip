@@ -6,6 +6,7 @@
 #include <iostream>
 #include <map>
 #include <random>
+#include <thread>
 
 #include <wf/windflow_gpu.hpp>
 
@@ -95,9 +96,10 @@ struct Gen {
 struct StridedGen {
     const vector<tuple_t>* st;
     size_t stride;
+    size_t offset = 0;  // lanes of other ranks come first
     size_t pos = (size_t)-1;
     bool operator()(tuple_t& t, RuntimeContext& rc) {
-        if (pos == (size_t)-1) pos = rc.getReplicaIndex();
+        if (pos == (size_t)-1) pos = offset + rc.getReplicaIndex();
         t = (*st)[pos];
         pos += stride;
         return pos < st->size();
@@ -500,6 +502,51 @@ int main(int argc, char** argv) {
                  << " " << exp_b_cnt << ")" << (ok ? "  OK" : "  FAILED") << endl;
             failures += !ok;
         }
+    }
+    // ---- J: DETERMINISTIC graphs ACROSS ranks: `world` ranks (threads over LocalTransport, one GPU), each with 2 source lanes that
+    //      overlap in time with every other lane of every rank; Exchange_GPU orders its output lanes by timestamp under the
+    //      low-watermark rule over all the lanes of all the ranks, so the keyed map behind it computes, for every tuple, the
+    //      running sum its key had at that point of the SEQUENTIAL stream ----
+    for (int world : {2, 3}) {
+        const size_t lanes_per_rank = 2, out_lanes = (size_t)dp(rng);
+        const size_t batch = 64 * (size_t)db(rng);
+        vector<int64_t> exp_val(stream.size());
+        {
+            map<size_t, int64_t> acc;
+            for (size_t i = 0; i < stream.size(); i++) exp_val[i] = (acc[stream[i].key] += stream[i].value);
+        }
+        auto fabric = std::make_shared<dist::LocalFabric>(world);
+        std::atomic<long> wrong{0}, cnt{0}, foreign{0};
+        vector<std::thread> threads;
+        for (int r = 0; r < world; r++) {
+            threads.emplace_back([&, r] {
+                auto tr = std::make_shared<dist::LocalTransport>(fabric, r);
+                PipeGraph g("keyed_j_rank" + to_string(r), Mode::DETERMINISTIC);
+                auto src = BatchSource_Builder(StridedGen{&stream, lanes_per_rank * (size_t)world, lanes_per_rank * (size_t)r}).withName("lanes")
+                               .withParallelism(lanes_per_rank).withBatch(batch).build_unique();
+                MultiPipe& mp = g.add_source(*src);
+                auto ex = ExchangeGPU_Builder<tuple_t>(tr).withName("exchange").withParallelism(lanes_per_rank).withLocalLanes(lanes_per_rank)
+                              .withOutputLanes(out_lanes).build_unique();
+                mp.add(*ex);
+                auto map = MapGPU_Builder(RunningSum()).withName("kmap").withParallelism(out_lanes).withScratchpad(8).withMaxKeys(keys).withKeyDisjointLanes()
+                               .build_unique();
+                mp.add(*map);
+                Sink sink = Sink_Builder([&, r](std::optional<tuple_t>& o) {
+                                if (o) {
+                                    if (o->value != exp_val[o->id]) wrong++;
+                                    if (gpu::keyby_destination(o->key, (uint32_t)world, gpu::HASH_SHIFT_RANKS) != (uint32_t)r) foreign++;
+                                    cnt++;
+                                }
+                            }).withParallelism(1).build();
+                mp.add_sink(sink);
+                g.run();
+            });
+        }
+        for (auto& t : threads) t.join();
+        const bool ok = (wrong == 0 && foreign == 0 && cnt == (long)n);
+        cout << "J deterministic across ranks world=" << world << " lanes=" << out_lanes << " batch=" << batch << " wrong " << wrong << " foreign " << foreign
+             << " cnt " << cnt << (ok ? "  OK" : "  FAILED") << endl;
+        failures += !ok;
     }
     // ---- E (whenever 2+ GPUs are visible; WF_SKIP_MULTI_GPU=1 opts out): scenario B with the replicas of the two keyed
     //      operators placed on different GPUs; the sub-batches of the device KeyBy cross GPUs with peer copies ----

@@ -150,6 +150,81 @@ def test_ysb_over_exchange(ext, world, sources, lanes, split_merge):
         assert all(s["exchange_tuples_sent"] > 0 for s in stats)
 
 
+@pytest.mark.parametrize("world,sources,lanes,split_merge", [(1, 2, 2, False), (2, 2, 1, False), (3, 2, 2, False), (2, 3, 2, True)])
+def test_ysb_over_exchange_deterministic_needs_no_delay(ext, world, sources, lanes, split_merge):
+    """DETERMINISTIC graph: the exchange releases every output lane in timestamp order under the low-watermark rule over all the
+    source lanes of all the ranks, so the windows need NO triggering delay to tolerate the lag between sources and ranks
+    (the DEFAULT graph above runs with 30 s) - and still no view is late."""
+    per_source, period = 400_000, 10
+    fabric = ext.LocalFabric(world)
+    stats = [None] * world
+    errors = []
+
+    def rank_main(r):
+        try:
+            pipe = ext.YsbPipeline(0, sources, 16384, period, 0, 4, lanes, ext.local_transport(fabric, r), split_merge, True)
+            pipe.step(per_source)
+            pipe.step(per_source)
+            pipe.close()
+            stats[r] = pipe.stats()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors
+    assert all(s is not None for s in stats)
+    views, results = _ysb_expected(2 * per_source, sources * world, period)
+    assert all(s["dropped"] == 0 and s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
+    assert sum(s["counted_views"] for s in stats) == views
+    assert sum(s["sink_tuples"] for s in stats) == results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_win_agg_deterministic_across_ranks(ext, world):
+    """count-based windows over keys that EVERY source of EVERY rank emits: only a total order of the job's tuples makes the
+    windows well defined.  The deterministic exchange provides it (timestamp, then source rank, then arrival), and the result is
+    the same whatever the number of ranks: the stream is the union of world x 2 sources that each emit key k at times k, k + K, ..."""
+    n_sources, n_keys, per_source, win, slide = 2, 40, 30_000, 8, 2
+    fabric = ext.LocalFabric(world)
+    stats = [None] * world
+    errors = []
+
+    def rank_main(r):
+        try:
+            # shared keys, DETERMINISTIC, count-based windows
+            pipe = ext.WinAggPipeline(0, n_sources, 2048, n_keys, win, slide, False, 0, 4, ext.local_transport(fabric, r), 2, 0, 1.3, True, True)
+            pipe.step(per_source)
+            pipe.close()
+            stats[r] = pipe.stats()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors
+    # every source emits the same (key, ts, value) sequence: at every timestamp a key receives S = world * n_sources tuples
+    # with the same value, so in the total order the key's stream is v0 x S, v1 x S, ... and the windows follow in closed form
+    S = world * n_sources
+    seq = np.arange(per_source)
+    total, windows = 0.0, 0
+    for k in range(n_keys):
+        v = np.repeat((seq[k::n_keys] & 1023).astype(np.float64), S)
+        c = np.concatenate([[0.0], np.cumsum(v)])
+        for lw in range(math.ceil(len(v) / slide)):
+            total += c[min(len(v), slide * lw + win)] - c[slide * lw]
+            windows += 1
+    assert sum(s["sink_tuples"] for s in stats) == windows
+    assert sum(s["sink_value_sum"] for s in stats) == pytest.approx(total, rel=1e-12)
+    assert all(s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

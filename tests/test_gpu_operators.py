@@ -52,8 +52,9 @@ def test_keyed_gpu_operators_and_device_keyby(n, keys):
     """Keyed Map_GPU / Filter_GPU (per-key scratchpad state) and Key_FFAT_GPU behind the device KeyBy emitter."""
     out = run_keyed_cpp([n, keys, 2])
     # scenarios A, H (keyed_scan: tuples, batches), B, C, D, G (device split/merge), F x 2 runs (+ E on a box with 2+ GPUs)
-    assert out.count("  OK") >= 24 and "FAILED" not in out
+    assert out.count("  OK") >= 26 and "FAILED" not in out
     assert out.count("H keyed_scan") == 4 and out.count("G device split/merge") == 2 and out.count("I deterministic") == 8
+    assert out.count("J deterministic across ranks") == 2  # world 2 and 3 over LocalTransport
 
 
 # the copy / synchronisation policies that are not the default (wf/gpu/hip_utils.hpp) must stay correct

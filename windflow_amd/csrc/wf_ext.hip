@@ -837,9 +837,9 @@ public:
     // split_merge: the events are split on the device by ad type into two branches, each with its own Filter_GPU -> Map_GPU(join),
     // and the branches are merged again in front of the exchange / aggregation (BASELINE.json config 5)
     YsbPipeline(int gpu_id, size_t n_sources, size_t batch_len, uint64_t period_us, uint64_t delay_us, size_t inflight, size_t agg_replicas,
-                std::shared_ptr<dist::Transport> transport = nullptr, bool split_merge = false)
+                std::shared_ptr<dist::Transport> transport = nullptr, bool split_merge = false, bool deterministic = false)
         : n_sources_(n_sources), n_sinks_(agg_replicas ? agg_replicas : 1), gates_(new wfbench::StepGate[n_sources]),
-          graph_("ysb_gpu", Mode::DEFAULT) {
+          graph_("ysb_gpu", deterministic ? Mode::DETERMINISTIC : Mode::DEFAULT) {
         auto totals = totals_ = std::make_shared<YsbTotals>();
         auto barrier = barrier_ = std::make_shared<wfbench::StepBarrier>();
         const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
@@ -1135,9 +1135,9 @@ PYBIND11_MODULE(_C, m) {
         .def("reset_latency", &WinSeqPipeline::reset_latency)
         .def("dot", &WinSeqPipeline::dot);
     py::class_<YsbPipeline>(m, "YsbPipeline")
-        .def(py::init<int, size_t, size_t, uint64_t, uint64_t, size_t, size_t, std::shared_ptr<dist::Transport>, bool>(), py::arg("gpu_id"),
+        .def(py::init<int, size_t, size_t, uint64_t, uint64_t, size_t, size_t, std::shared_ptr<dist::Transport>, bool, bool>(), py::arg("gpu_id"),
              py::arg("n_sources"), py::arg("batch_len"), py::arg("period_us") = 1, py::arg("delay_us") = 1000000, py::arg("inflight") = 4,
-             py::arg("agg_replicas") = 1, py::arg("transport") = nullptr, py::arg("split_merge") = false)
+             py::arg("agg_replicas") = 1, py::arg("transport") = nullptr, py::arg("split_merge") = false, py::arg("deterministic") = false)
         .def("step", &YsbPipeline::step)
         .def("steps", &YsbPipeline::steps)
         .def("close", &YsbPipeline::close)

@@ -108,6 +108,9 @@ public:
     // operators do, through the device KeyBy endpoint); otherwise batches coming from a different number of lanes are
     // turned back into tuples so that the ordering nodes of the tuple world apply
     virtual bool merges_batch_lanes_in_order() const { return false; }
+    // true for a keyed operator that was promised key-disjoint batch lanes (withKeyDisjointLanes): lane i feeds replica i
+    // directly, whatever routing the operator would use on tuples
+    virtual bool takes_batch_lanes_one_to_one() const { return false; }
     // statistics of every replica (filled at the end of the run)
     virtual std::vector<Stats_Record> get_StatsRecords() const {
         std::lock_guard<std::mutex> l(hub_->m);

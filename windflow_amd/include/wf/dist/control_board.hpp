@@ -40,7 +40,8 @@ struct ControlRow {
     uint64_t capacity;    // largest batch capacity the rank has seen (sizes the receive slabs)
     uint64_t send_base;   // pull transports: address of the rank's send buffer for this round (in the sender's address space)
     uint64_t ipc_offset;  // IpcTransport: offset of send_base inside the allocation named by ipc_handle
-    uint64_t aux;
+    uint64_t aux;         // DETERMINISTIC graphs: greatest timestamp the rank has sent so far (`watermark` is what it claims to be complete)
+    uint64_t held;        // DETERMINISTIC graphs: tuples the rank has received but may not release yet (senders that run ahead slow down)
     unsigned char ipc_handle[64];  // IpcTransport: hipIpcMemHandle_t of the allocation that holds the send buffer
 };
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ControlRow::ipc_handle too small");

@@ -44,8 +44,13 @@ public:
     }
     size_t getOutputLanes() const { return xcfg_.out_lanes; }
 
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode) override {
-        return exchange_stages<tuple_t>(g, tr_, name_, cfg_, xcfg_, kind_, hub_, xstats_, closing_);
+    // DETERMINISTIC graphs: the exchange is an ordering point - every output lane carries its tuples in timestamp order, released
+    // under the low-watermark rule over every producer lane of every rank (exchange_nodes.hpp)
+    bool merges_batch_lanes_in_order() const override { return true; }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override {
+        ExchangeConfig x = xcfg_;
+        if (m == Mode::DETERMINISTIC) x.deterministic = true;
+        return exchange_stages<tuple_t>(g, tr_, name_, cfg_, x, kind_, hub_, xstats_, closing_);
     }
 
 private:

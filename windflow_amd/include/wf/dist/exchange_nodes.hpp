@@ -82,7 +82,7 @@ struct ExchangeStats {
 // What a partition lane hands to the rank's endpoint
 struct ExchangeBundle {
     uint64_t arrived_us = 0;                // when the endpoint got it
-    size_t consumed[dist::MAX_LANES] = {};  // deterministic mode: tuples of every lane segment already released
+    size_t consumed[dist::MAX_WORLD * dist::MAX_LANES] = {};  // deterministic mode: tuples of every destination segment already released
     gpu::Batch* packed = nullptr;           // the batch grouped by destination (rank, lane)
     volatile uint32_t* offsets = nullptr;   // pinned: world * lanes + 1 offsets into `packed`, valid once packed->ready has fired
     gpu::Batch* passthrough = nullptr;      // one rank, one lane: the batch itself
@@ -214,6 +214,71 @@ template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS) det_gather_kernel(const T* work, const uint32_t* perm, T* out, uint32_t first, uint32_t count) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) out[i] = work[perm[first + i]];
 }
+// ---- deterministic merge across ranks ----
+// Sort key of a pending tuple: (lane', timestamp - base, source rank).  lane' is the output lane of the tuple when it may be
+// released (timestamp <= W) and n_lanes when it has to wait: ONE stable sort then leaves the released tuples of every lane in
+// (timestamp, rank, arrival) order, followed by the tuples that stay pending in their arrival order.  `shift`: which 32 bits
+// of the key are produced (keys wider than 32 bits are sorted least significant half first).
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    xdet_keys_kernel(const T* pend, const uint32_t* src_rank, uint32_t n, uint64_t W, uint64_t base, uint32_t n_lanes, int ts_bits, int rank_bits, int shift,
+                     const uint32_t* perm, uint32_t* keys, uint32_t* idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t src = perm ? perm[i] : i;
+        const T t = pend[src];
+        const uint64_t ts = (uint64_t)std::get<2>(t.getControlFields());
+        unsigned long long k;
+        if (ts <= W) {
+            const uint64_t h = mix64((uint64_t)std::get<0>(t.getControlFields()));
+            const unsigned long long lane = ((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes;
+            const unsigned long long rel = ts > base ? ts - base : 0ull;
+            k = (lane << (ts_bits + rank_bits)) | (rel << rank_bits) | (unsigned long long)src_rank[src];
+        } else {
+            k = (unsigned long long)n_lanes << (ts_bits + rank_bits);
+        }
+        keys[i] = (uint32_t)(k >> shift);
+        idx[i] = src;
+    }
+}
+// where the lanes (and the pending rest) begin in the sorted order: offsets[l] = first position of lane' >= l, offsets[n_lanes + 1] = n;
+// written straight to pinned host memory
+template <typename T>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    xdet_offsets_kernel(const T* pend, const uint32_t* perm, uint32_t n, uint64_t W, uint32_t n_lanes, volatile uint32_t* offsets) {
+    auto lane_of = [&](uint32_t pos) -> uint32_t {
+        const T t = pend[perm[pos]];
+        if ((uint64_t)std::get<2>(t.getControlFields()) > W) return n_lanes;
+        const uint64_t h = mix64((uint64_t)std::get<0>(t.getControlFields()));
+        return (uint32_t)(((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes);
+    };
+    if (n == 0) {
+        if (blockIdx.x == 0)
+            for (uint32_t x = threadIdx.x; x <= n_lanes + 1; x += blockDim.x) offsets[x] = 0;
+        return;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = lane_of(i);
+        const uint32_t first = (i == 0) ? 0u : lane_of(i - 1) + 1u;
+        for (uint32_t x = first; x <= d; x++) offsets[x] = i;
+        if (i == n - 1)
+            for (uint32_t x = d + 1; x <= n_lanes + 1; x++) offsets[x] = n;
+    }
+}
+struct XdetRankOff {
+    uint32_t off[dist::MAX_WORLD + 1];
+};
+// source rank of the tuples that arrived in this round (chunk r of the staging area came from rank r)
+__global__ void __launch_bounds__(BLOCK_THREADS) xdet_fill_ranks_kernel(uint32_t* ranks, XdetRankOff o, uint32_t world) {
+    const uint32_t n = o.off[world];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t r = 0;
+        while (r + 1 < world && i >= o.off[r + 1]) r++;
+        ranks[i] = r;
+    }
+}
+__global__ void __launch_bounds__(BLOCK_THREADS) xdet_gather_u32_kernel(const uint32_t* src, const uint32_t* perm, uint32_t* dst, uint32_t first, uint32_t count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) dst[i] = src[perm[first + i]];
+}
 }  // namespace gpu
 
 // ---- stage 1: partition lanes (parallel) ------------------------------------------------------
@@ -280,8 +345,6 @@ public:
         if (!xstats_) xstats_ = std::make_shared<ExchangeStats>();
         if (world() > dist::MAX_WORLD) gpu::failwith("Exchange_GPU: world size above MAX_WORLD");
         if (xcfg_.out_lanes == 0 || xcfg_.out_lanes > (size_t)dist::MAX_LANES) gpu::failwith("Exchange_GPU: between 1 and 16 output lanes");
-        if (xcfg_.deterministic && world() > 1)
-            gpu::failwith("Exchange_GPU: DETERMINISTIC graphs are ordered inside one rank only (the watermark rule needs every producer of a key)");
         cfg_.gpu_id = cfg.device_for(0);
     }
     void svc_init() override {
@@ -309,9 +372,12 @@ public:
         if (!xcfg_.deterministic || !stream_) return;
         det_init();
         det_ended_[(size_t)channel] = true;
-        det_release(false);
+        if (world() > 1)
+            pump();
+        else
+            det_release(false);
     }
-    bool wants_idle() const override { return !xcfg_.deterministic; }
+    bool wants_idle() const override { return !xcfg_.deterministic || world() > 1; }
     void on_idle() override {
         if (!finished_) pump();
     }
@@ -319,12 +385,13 @@ public:
         // end of my stream: keep answering rounds until everybody is done
         done_ = true;
         if (!stream_) return;  // never started
-        if (xcfg_.deterministic) {
+        if (xcfg_.deterministic && world() == 1) {
             det_init();
             det_release(true);
             finished_ = true;
             return;
         }
+        if (xcfg_.deterministic) det_init();
         while (!finished_) {
             if (!pump()) std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
@@ -338,6 +405,8 @@ public:
         if (stream_) stream_->sync();
         if (det_counts_) (void)hipHostFree((void*)det_counts_);
         if (det_segs_) (void)hipHostFree(det_segs_);
+        if (xd_offsets_) (void)hipHostFree((void*)xd_offsets_);
+        xd_offsets_ = nullptr;
         det_counts_ = nullptr;
         det_segs_ = nullptr;
         tables_.reset();
@@ -424,7 +493,7 @@ private:
         // (a round's slot on the board and in the transport is reused DEPTH rounds later: not before its send buffers are back)
         while (pub_ - col_ < WINDOW && board.can_publish(pub_) && (sent_.empty() || sent_.front().first + dist::ControlBoard::DEPTH > pub_)) {
             // a peer that has opened this round is waiting for this rank: answer with what is there
-            if (staged_.size() < 2 && stage_round(board.anyone_published(pub_))) progress = true;
+            if (staged_.size() < 2 && (xcfg_.deterministic ? xdet_stage() : stage_round(board.anyone_published(pub_)))) progress = true;
             dist::ControlRow row{};
             gpu::Batch* buf = nullptr;
             if (!staged_.empty()) {
@@ -438,8 +507,11 @@ private:
                     break;  // nothing to say yet, nobody is waiting for this rank, and the last round is recent
                 row.step = local_step_done_;
                 row.capacity = my_cap_;
+                row.watermark = xd_sent_w_;
+                row.aux = xd_max_ts_;
             }
-            row.done = (done_ && pending_.empty() && staged_.empty()) ? 1 : 0;
+            row.held = xd_held_;
+            row.done = (done_ && pending_.empty() && staged_.empty() && xdet_drained()) ? 1 : 0;
             board.publish(pub_, row);
             open_.push_back(buf);
             pub_++;
@@ -484,6 +556,12 @@ private:
             min_step = std::min(min_step, row.step);
             rank_wm_[r] = std::max(rank_wm_[r], row.watermark);
             rank_done_[r] = row.done != 0;
+            rank_aux_[r] = std::max(rank_aux_[r], row.aux);
+            if (row.step > rank_step_[r]) {  // everything of the rank's steps up to row.step has a timestamp <= what it has sent so far
+                rank_step_[r] = row.step;
+                rank_step_ts_[r] = rank_aux_[r];
+            }
+            xd_peer_held_ = r == 0 ? row.held : std::max<uint64_t>(xd_peer_held_, row.held);
             cap_ = std::max<size_t>(cap_, (size_t)row.capacity);
             if (row.created_ns != 0 && chunk[r] > 0) created = created == 0 ? row.created_ns : std::min(created, row.created_ns);
         }
@@ -493,14 +571,17 @@ private:
             if (!rank_done_[r]) wm = std::min(wm, rank_wm_[r]);
         if (wm == UINT64_MAX)
             for (int r = 0; r < world; r++) wm = (r == 0) ? rank_wm_[r] : std::max(wm, rank_wm_[r]);
-        const uint64_t step_out = take_global_step(min_step);
+        const uint64_t step_out = xcfg_.deterministic ? 0 : take_global_step(min_step);
         gpu::Batch* stage = nullptr;
+        tuple_t* land = nullptr;  // where the peers' chunks land, back to back
+        if (xcfg_.deterministic) land = xdet_reserve(total);
         if (any_traffic) {
-            if (total > 0) {
+            if (total > 0 && !xcfg_.deterministic) {
                 // the staging slab grows with the traffic (a rank that owns the hot keys receives more than its share)
                 size_t want = std::max<size_t>(2 * group_ * std::max<size_t>(cap_, 1), 1);
                 while (want < total) want *= 2;
                 stage = acquire(stage_pool_, stage_cap_, want, cfg_.pool_slabs + 2);
+                land = stage->template data<tuple_t>();
             }
             size_t off = 0, mine_before = 0;
             uint64_t sent = 0;
@@ -514,7 +595,7 @@ private:
                 }
                 mine_before += to_p;
                 if (chunk[p] > 0) {
-                    sl.recv[p] = stage->template data<tuple_t>() + off;
+                    sl.recv[p] = land + off;
                     sl.recv_bytes[p] = chunk[p] * sizeof(tuple_t);
                     off += chunk[p];
                 }
@@ -529,6 +610,12 @@ private:
         // every rank calls exchange() every round, in round order (the collectives of a communicator must line up)
         tr_->exchange(round, sl, rows, s);
         sent_.push_back({round, buf});
+        if (xcfg_.deterministic) {
+            xdet_receive(chunk, total, wm, all_done, min_step, created, s);
+            xstats_->rounds++;
+            if (all_done && !any_traffic && xd_held_ == 0) finished_ = true;
+            return;
+        }
         if (total > 0 || step_out != 0) {
             src_list_t lane_src[dist::MAX_LANES];
             size_t src = 0;
@@ -676,7 +763,10 @@ private:
         det_q_[c].push_back(b);
         det_wm_[c] = std::max(det_wm_[c], b->hdr.watermark);
         det_seen_[c] = true;
-        det_release(false);
+        if (world() > 1)
+            pump();
+        else
+            det_release(false);
     }
     // release what the watermark rule allows (everything at end of stream)
     void det_release(bool final) {
@@ -863,6 +953,294 @@ private:
         }
     }
 
+    // ---- deterministic mode across ranks ------------------------------------------------------------------------
+    // Two levels of the low-watermark rule (reference: wf/ordering_node.hpp:154-193, per input channel of ONE node):
+    //  * sending side: W_local = least of the latest watermarks of this rank's producer lanes.  A round carries every pending
+    //    tuple with timestamp <= W_local, grouped by destination (not sorted: the receiver sorts anyway), and its row claims
+    //    W_local: "everything this rank will ever send with a timestamp <= W_local has been sent".
+    //  * receiving side: W = least of the ranks' claims (ranks that are done do not count).  Everything received so far with a
+    //    timestamp <= W is released, per output lane, in (timestamp, source rank, arrival) order with ONE radix sort; the rest
+    //    stays in a pending buffer on the device - the chunks of a round land directly behind it.
+    // Senders that run ahead of the slowest rank see the receivers' pending buffers grow (ControlRow::held) and hold their
+    // data back (they keep publishing their watermark), so the buffers stay bounded.
+    bool xdet_drained() const {
+        if (!xcfg_.deterministic || world() == 1) return true;
+        for (auto& q : det_q_)
+            if (!q.empty()) return false;
+        return true;
+    }
+    // stage the next round of this rank; true if a round was staged
+    bool xdet_stage() {
+        det_init();
+        const size_t L = xcfg_.out_lanes, D = (size_t)world() * L;
+        hipStream_t s = stream_->get();
+        uint64_t W = UINT64_MAX;
+        bool any_open = false;
+        for (size_t c = 0; c < det_q_.size(); c++) {
+            if (det_ended_[c]) continue;
+            any_open = true;
+            if (!det_seen_[c]) return false;  // a producer that has said nothing yet holds everything back
+            W = std::min(W, det_wm_[c]);
+        }
+        if (done_ || !any_open) W = UINT64_MAX;
+        const bool advanced = !xd_staged_once_ || W > xd_sent_w_;
+        if (!advanced) return false;
+        // a rank that is ahead while some receiver sits on a large pending buffer keeps its data for now
+        if (W != UINT64_MAX && xd_peer_held_ > XD_HELD_LIMIT && xd_sent_w_ > xd_released_w_) return false;
+        struct Piece {
+            ExchangeBundle* b;
+            size_t dest, off, take;
+            int probe;
+        };
+        std::vector<Piece> pieces;
+        uint32_t n_probe = 0;
+        for (auto& q : det_q_)
+            for (ExchangeBundle* b : q) {
+                b->packed->ready.host_sync();  // the offsets are on the host from here on
+                const uint64_t upper = b->hdr.reserved[2] != 0 ? b->hdr.reserved[2] : b->hdr.watermark;
+                xd_max_ts_ = std::max(xd_max_ts_, W == UINT64_MAX ? upper : std::min(W, upper));
+                const bool whole = upper <= W;
+                for (size_t d = 0; d < D; d++) {
+                    const size_t lo = b->offsets[d] + b->consumed[d], end = b->offsets[d + 1];
+                    if (lo >= end) continue;
+                    Piece pc{b, d, lo, end - lo, -1};
+                    if (!whole) {
+                        if (n_probe >= DET_MAX_SEGS) gpu::failwith("Exchange_GPU: too many pending segments in deterministic mode");
+                        det_segs_[n_probe] = gpu::SegCopy{b->packed->template data<tuple_t>() + lo, nullptr, end - lo};
+                        pc.probe = (int)n_probe++;
+                    }
+                    pieces.push_back(pc);
+                }
+            }
+        if (n_probe > 0) {
+            if (!det_probe_stream_) det_probe_stream_.reset(new gpu::Stream());
+            hipStream_t ps = det_probe_stream_->get();
+            hipLaunchKernelGGL((gpu::det_count_le_kernel<tuple_t>), dim3((n_probe + gpu::BLOCK_THREADS - 1) / gpu::BLOCK_THREADS), dim3(gpu::BLOCK_THREADS), 0, ps,
+                               det_segs_, n_probe, W, det_counts_);
+            WF_HIP_CHECK(hipStreamSynchronize(ps));
+            for (Piece& pc : pieces)
+                if (pc.probe >= 0) pc.take = det_counts_[pc.probe];
+        }
+        staged_.emplace_back();
+        Staged& st = staged_.back();
+        size_t total = 0;
+        for (const Piece& pc : pieces) {
+            st.row.counts[pc.dest] += (uint32_t)pc.take;
+            total += pc.take;
+            if (pc.take > 0 && pc.b->hdr.created_ns != 0)
+                st.row.created_ns = st.row.created_ns == 0 ? pc.b->hdr.created_ns : std::min(st.row.created_ns, pc.b->hdr.created_ns);
+        }
+        for (auto& q : det_q_)
+            for (ExchangeBundle* b : q) my_cap_ = std::max(my_cap_, b->capacity);
+        if (total > 0) {
+            size_t want = std::max<size_t>(std::max(send_cap_, group_ * std::max<size_t>(my_cap_, 1)), 1);
+            while (want < total) want *= 2;
+            st.buf = acquire(send_pool_, send_cap_, want, dist::ControlBoard::DEPTH + 4);
+            tables_->clear();
+            size_t run = 0;
+            std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.dest < b.dest; });  // destination-major, arrival order inside
+            for (const Piece& pc : pieces) {
+                if (pc.take == 0) continue;
+                tables_->segs.push_back({pc.b->packed->template data<tuple_t>() + pc.off, st.buf->template data<tuple_t>() + run, pc.take});
+                run += pc.take;
+            }
+            tables_->template launch<tuple_t>(s);
+            st.merged.reset(new gpu::Event());
+            st.merged->record(s);
+            tr_->describe_send(st.buf->slab, st.buf->template data<tuple_t>(), st.row);
+        }
+        for (Piece& pc : pieces) pc.b->consumed[pc.dest] += pc.take;
+        // bundles that have given everything go back to their lanes
+        for (auto& q : det_q_)
+            while (!q.empty()) {
+                ExchangeBundle* b = q.front();
+                bool all = true;
+                for (size_t d = 0; d < D && all; d++) all = b->offsets[d] + b->consumed[d] >= b->offsets[d + 1];
+                if (!all) break;
+                if (b->hdr.reserved[0] != 0) note_local_punctuation(b->hdr.reserved[0]);
+                b->packed->release(s);
+                delete b;
+                q.pop_front();
+                xstats_->bundles++;
+            }
+        xd_sent_w_ = W;
+        xd_staged_once_ = true;
+        st.row.watermark = W;
+        st.row.aux = xd_max_ts_;
+        st.row.step = local_step_done_;
+        st.row.capacity = my_cap_;
+        return true;
+    }
+    // room for `incoming` tuples behind the pending ones; returns where they land
+    tuple_t* xdet_reserve(size_t incoming) {
+        const size_t need = xd_held_ + incoming;
+        if (need > xd_cap_) {
+            WF_HIP_CHECK(hipStreamSynchronize(stream_->get()));  // the old buffers may still be read
+            size_t cap = std::max<size_t>(xd_cap_, 1 << 16);
+            while (cap < need) cap *= 2;
+            gpu::DeviceBuffer<tuple_t> np(cap);
+            gpu::DeviceBuffer<uint32_t> nr(cap);
+            if (xd_held_ > 0) {
+                WF_HIP_CHECK(hipMemcpyAsync(np.data(), xd_pend_[xd_cur_].data(), xd_held_ * sizeof(tuple_t), hipMemcpyDeviceToDevice, stream_->get()));
+                WF_HIP_CHECK(hipMemcpyAsync(nr.data(), xd_rank_[xd_cur_].data(), xd_held_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_->get()));
+                WF_HIP_CHECK(hipStreamSynchronize(stream_->get()));
+            }
+            xd_pend_[xd_cur_] = std::move(np);
+            xd_rank_[xd_cur_] = std::move(nr);
+            xd_pend_[1 - xd_cur_] = gpu::DeviceBuffer<tuple_t>(cap);
+            xd_rank_[1 - xd_cur_] = gpu::DeviceBuffer<uint32_t>(cap);
+            xd_keys_ = gpu::DeviceBuffer<uint32_t>(cap);
+            xd_idx_ = gpu::DeviceBuffer<uint32_t>(cap);
+            xd_keys2_ = gpu::DeviceBuffer<uint32_t>(cap);
+            xd_idx2_ = gpu::DeviceBuffer<uint32_t>(cap);
+            xd_cap_ = cap;
+        }
+        return xd_pend_[xd_cur_].data() + xd_held_;
+    }
+    // the chunks of a round have been enqueued behind the pending tuples: release what the ranks' claims allow
+    void xdet_receive(const size_t* chunk, size_t total, uint64_t W, bool all_done, uint64_t min_step, uint64_t created, hipStream_t s) {
+        const int world = tr_->world();
+        const size_t L = xcfg_.out_lanes;
+        if (all_done) W = UINT64_MAX;
+        if (!det_n_dev_.data()) det_n_dev_.resize(1);
+        if (xd_offsets_ == nullptr) WF_HIP_CHECK(hipHostMalloc((void**)&xd_offsets_, (dist::MAX_LANES + 2) * sizeof(uint32_t), hipHostMallocDefault));
+        if (created != 0) xd_created_ = xd_created_ == 0 ? created : std::min(xd_created_, created);
+        if (total > 0) {
+            gpu::XdetRankOff ro{};
+            size_t acc = 0;
+            for (int r = 0; r < world; r++) {
+                ro.off[r] = (uint32_t)acc;
+                acc += chunk[r];
+            }
+            ro.off[world] = (uint32_t)acc;
+            hipLaunchKernelGGL(gpu::xdet_fill_ranks_kernel, dim3(gpu::grid_for(total)), dim3(gpu::BLOCK_THREADS), 0, s, xd_rank_[xd_cur_].data() + xd_held_, ro,
+                               (uint32_t)world);
+            xstats_->tuples_received += 0;  // (counted by run_round)
+        }
+        const size_t n = xd_held_ + total;
+        // which steps may be announced: every rank has completed them AND nothing of them can still be pending
+        uint64_t step_ts = 0;
+        for (int r = 0; r < world; r++) step_ts = std::max(step_ts, rank_step_ts_[r]);
+        const bool nothing_new = n == 0 || (W != UINT64_MAX && xd_released_once_ && W <= xd_released_w_);
+        if (nothing_new) {
+            // (the watermark did not move: the pending tuples stay; a step can still complete when nothing is pending)
+            xd_held_ = n;
+            if (n == 0) xdet_announce(min_step, W == UINT64_MAX ? xd_released_w_ : std::max(W, xd_released_w_), s);
+            return;
+        }
+        if (n > UINT32_MAX) gpu::failwith("Exchange_GPU: too many pending tuples in deterministic mode");
+        const uint32_t n32 = (uint32_t)n;
+        const uint64_t base = xd_released_w_;
+        uint64_t hi = W;
+        if (W == UINT64_MAX) {
+            hi = base;
+            for (int r = 0; r < world; r++) hi = std::max(hi, rank_aux_[r]);
+        }
+        const uint64_t range = hi >= base ? hi - base : 0;
+        int ts_bits = 1, lane_bits = 1, rank_bits = 0;
+        while (ts_bits < 64 && (range >> ts_bits) != 0) ts_bits++;
+        while ((size_t(1) << lane_bits) < L + 1) lane_bits++;
+        while ((1 << rank_bits) < world) rank_bits++;
+        if (ts_bits + lane_bits + rank_bits > 64) gpu::failwith("Exchange_GPU: timestamps of one deterministic release span more than 2^50");
+        const tuple_t* P = xd_pend_[xd_cur_].data();
+        const uint32_t* PR = xd_rank_[xd_cur_].data();
+        hipLaunchKernelGGL(gpu::det_set_u32_kernel, dim3(1), dim3(1), 0, s, det_n_dev_.data(), n32);
+        const unsigned grid = gpu::grid_for(n);
+        const int total_bits = ts_bits + lane_bits + rank_bits;
+        const uint32_t* perm = nullptr;
+        hipLaunchKernelGGL((gpu::xdet_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, P, PR, n32, W, base, (uint32_t)L, ts_bits, rank_bits, 0,
+                           (const uint32_t*)nullptr, xd_keys_.data(), xd_idx_.data());
+        if (total_bits <= 32) {
+            perm = det_sorter_.sort(xd_keys_.data(), xd_idx_.data(), det_n_dev_.data(), n, total_bits, s).vals;
+        } else {
+            auto low = det_sorter_.sort(xd_keys_.data(), xd_idx_.data(), det_n_dev_.data(), n, 32, s);
+            hipLaunchKernelGGL((gpu::xdet_keys_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, P, PR, n32, W, base, (uint32_t)L, ts_bits, rank_bits,
+                               32, (const uint32_t*)low.vals, xd_keys2_.data(), xd_idx2_.data());
+            perm = det_sorter2_.sort(xd_keys2_.data(), xd_idx2_.data(), det_n_dev_.data(), n, total_bits - 32, s).vals;
+        }
+        hipLaunchKernelGGL((gpu::xdet_offsets_kernel<tuple_t>), dim3(grid), dim3(gpu::BLOCK_THREADS), 0, s, P, perm, n32, W, (uint32_t)L, xd_offsets_);
+        WF_HIP_CHECK(hipStreamSynchronize(s));  // the lane counts size the batches
+        uint32_t off[dist::MAX_LANES + 2];
+        for (size_t l = 0; l <= L + 1; l++) off[l] = xd_offsets_[l];
+        const size_t held = off[L + 1] - off[L];
+        xdet_lane_pool();
+        // may the step be announced with this release?  (decided before the batches are cut: the punctuation rides on the last one)
+        uint64_t step_out = 0;
+        if (min_step != UINT64_MAX && min_step > announced_step_ && (held == 0 || hi >= step_ts)) step_out = take_global_step(min_step);
+        for (size_t l = 0; l < L; l++) {
+            const size_t cnt_l = off[l + 1] - off[l];
+            if (cnt_l == 0 && step_out == 0 && hi <= base) continue;
+            size_t done = 0;
+            do {
+                const size_t cnt = std::min(cnt_l - done, lane_cap_);
+                gpu::Batch* out = lane_pool_->acquire(s);
+                out->host_hdr = gpu::BatchHeader{};
+                out->host_hdr.count = (uint32_t)cnt;
+                out->host_hdr.source_id = (uint32_t)rank();
+                const bool last = done + cnt == cnt_l;
+                out->host_hdr.watermark = last ? hi : base;
+                out->host_hdr.reserved[2] = last ? 0 : hi;
+                out->host_hdr.first_seq = seq_;
+                out->host_hdr.reserved[0] = last ? step_out : 0;
+                out->host_hdr.created_ns = xd_created_;
+                out->count_on_host = true;
+                tables_->clear();
+                tables_->hdrs.push_back(gpu::HdrWrite{out->host_hdr, out->header(), {}});
+                tables_->template launch<tuple_t>(s);
+                if (cnt > 0)
+                    hipLaunchKernelGGL((gpu::det_gather_kernel<tuple_t>), dim3(gpu::grid_for(cnt)), dim3(gpu::BLOCK_THREADS), 0, s, P, perm,
+                                       out->template data<tuple_t>(), (uint32_t)(off[l] + done), (uint32_t)cnt);
+                out->ready.record(s);
+                emit_to(out, l);
+                xstats_->lane_batches++;
+                seq_ += cnt;
+                done += cnt;
+            } while (done < cnt_l);
+        }
+        // what stays pending moves to the front of the other buffer (arrival order kept)
+        if (held > 0) {
+            hipLaunchKernelGGL((gpu::det_gather_kernel<tuple_t>), dim3(gpu::grid_for(held)), dim3(gpu::BLOCK_THREADS), 0, s, P, perm, xd_pend_[1 - xd_cur_].data(),
+                               off[L], (uint32_t)held);
+            hipLaunchKernelGGL(gpu::xdet_gather_u32_kernel, dim3(gpu::grid_for(held)), dim3(gpu::BLOCK_THREADS), 0, s, PR, perm, xd_rank_[1 - xd_cur_].data(), off[L],
+                               (uint32_t)held);
+        } else {
+            xd_created_ = 0;
+        }
+        xd_cur_ = 1 - xd_cur_;
+        xd_held_ = held;
+        xd_released_w_ = hi;
+        xd_released_once_ = true;
+    }
+    void xdet_lane_pool() {
+        if (lane_cap_ != 0) return;
+        const size_t L = xcfg_.out_lanes;
+        const size_t cap = std::max<size_t>(std::max(cap_, my_cap_), 1);
+        lane_cap_ = std::max(cap, (2 * group_ * cap + L - 1) / L);
+        lane_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(tuple_t), lane_cap_, std::max<size_t>(cfg_.pool_slabs, 3) * L));
+    }
+    // a step completes although this round released nothing: empty batches carry the punctuation
+    void xdet_announce(uint64_t min_step, uint64_t wm, hipStream_t s) {
+        if (min_step == UINT64_MAX || min_step <= announced_step_) return;
+        const uint64_t step_out = take_global_step(min_step);
+        if (step_out == 0) return;
+        xdet_lane_pool();
+        for (size_t l = 0; l < xcfg_.out_lanes; l++) {
+            gpu::Batch* out = lane_pool_->acquire(s);
+            out->host_hdr = gpu::BatchHeader{};
+            out->host_hdr.source_id = (uint32_t)rank();
+            out->host_hdr.watermark = wm;
+            out->host_hdr.first_seq = seq_;
+            out->host_hdr.reserved[0] = step_out;
+            out->count_on_host = true;
+            tables_->clear();
+            tables_->hdrs.push_back(gpu::HdrWrite{out->host_hdr, out->header(), {}});
+            tables_->template launch<tuple_t>(s);
+            out->ready.record(s);
+            emit_to(out, l);
+            xstats_->lane_batches++;
+        }
+    }
+
     gpu::Batch* acquire(std::unique_ptr<gpu::BatchPool>& pool, size_t& pool_cap, size_t need, size_t slabs) {
         if (!pool || pool_cap < need) {
             // batches of the old pool may still be in flight: keep it alive until the end
@@ -924,6 +1302,16 @@ private:
     gpu::DeviceBuffer<tuple_t> det_work_;
     gpu::DeviceBuffer<uint32_t> det_keys_, det_idx_, det_keys2_, det_idx2_, det_n_dev_;
     gpu::RadixSorter det_sorter_, det_sorter2_;
+    // deterministic mode across ranks
+    static constexpr uint64_t XD_HELD_LIMIT = 32u << 20;  // pending tuples at a receiver from which the ranks that are ahead slow down
+    uint64_t xd_sent_w_ = 0, xd_max_ts_ = 0, xd_released_w_ = 0, xd_peer_held_ = 0, xd_created_ = 0;
+    bool xd_staged_once_ = false, xd_released_once_ = false;
+    uint64_t rank_aux_[dist::MAX_WORLD] = {}, rank_step_[dist::MAX_WORLD] = {}, rank_step_ts_[dist::MAX_WORLD] = {};
+    gpu::DeviceBuffer<tuple_t> xd_pend_[2];
+    gpu::DeviceBuffer<uint32_t> xd_rank_[2], xd_keys_, xd_idx_, xd_keys2_, xd_idx2_;
+    int xd_cur_ = 0;
+    size_t xd_held_ = 0, xd_cap_ = 0;
+    volatile uint32_t* xd_offsets_ = nullptr;
 };
 
 // The two stages in front of a consumer with `lanes` replicas: (1) one packing node per producer, fused onto it;

@@ -1275,6 +1275,7 @@ public:
     std::vector<gpu::FFATCounters> getDeviceCounters() const { return *counters_; }
 
     bool merges_batch_lanes_in_order() const override { return !wcfg_.lanes_are_key_disjoint; }
+    bool takes_batch_lanes_one_to_one() const override { return wcfg_.lanes_are_key_disjoint; }
     // tuple producers fill batches themselves (count-based windows keep the reference's rule: DETERMINISTIC graphs only, which
     // the tuple path enforces)
     std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override {

@@ -534,6 +534,7 @@ public:
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override { return batch_adapter_factory<result_t>(cfg_.pool_slabs); }
 
     bool merges_batch_lanes_in_order() const override { return !kcfg_.lanes_are_key_disjoint; }
+    bool takes_batch_lanes_one_to_one() const override { return kcfg_.lanes_are_key_disjoint; }
     // tuple producers fill batches themselves; the device KeyBy then replaces the host routing (a custom routing function only
     // applies to the tuple path: WF_TUPLE_PATH=1)
     std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode) const override {

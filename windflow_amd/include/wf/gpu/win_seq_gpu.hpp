@@ -148,6 +148,7 @@ public:
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, std::move(routing), opt_level) {}
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
+    bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }
     std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }
     edge_kind_t output_kind() const override { return flat_ ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }
@@ -198,6 +199,7 @@ public:
         : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, ordered, opt_level) {}
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
+    bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }
     std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }
     edge_kind_t output_kind() const override { return batch_path() ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
     bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }

@@ -389,7 +389,8 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
     // them themselves; in front of anything else that is not fed lane by lane the batches become tuples again and the
     // ordering nodes do their work.
     if (mode == Mode::DETERMINISTIC && tail_kind_ != EDGE_TUPLE && !op.merges_batch_lanes_in_order() &&
-        (tails_.size() != op.getParallelism() || force_shuffle_ || fresh_from_split_ || op.getRoutingMode() != FORWARD))
+        (tails_.size() != op.getParallelism() || force_shuffle_ ||
+         !(op.getRoutingMode() == FORWARD || op.takes_batch_lanes_one_to_one())))  // (a branch of a device split keeps its lanes: port b of splitter i)
         adapt_tails([](edge_kind_t k) { return k == EDGE_TUPLE; });
     // upward adaptation: a batch operator behind a producer of tuples gets a Batcher fused onto every producer (see
     // Basic_Operator::input_batcher_factory) - unless the mode needs an order that only the tuple world's ordering nodes can
@@ -437,7 +438,7 @@ inline void MultiPipe::attach(Basic_Operator& op, bool try_chain) {
         // batch edges a branch is just one more output port of the device splitter: its work can stay in the splitter's thread)
         const bool can_chain = try_chain && stages.size() == 1 && s.routing == FORWARD && (!fresh_from_split_ || tail_kind_ != EDGE_TUPLE) &&
                                !force_shuffle_ && prev.size() == n;
-        const bool direct = !s.internal && s.routing == FORWARD && !fresh_from_split_ && !force_shuffle_ && prev.size() == n;
+        const bool direct = !s.internal && s.routing == FORWARD && (!fresh_from_split_ || tail_kind_ != EDGE_TUPLE) && !force_shuffle_ && prev.size() == n;
         if (can_chain) {
             // same thread as the producer (reference: chain_operator, pipegraph.hpp:1273-1318)
             for (size_t i = 0; i < n; i++) g.connect_fused(prev[i].node, prev[i].port, s.replicas[i]);

@@ -84,9 +84,9 @@ class Ysb(_Pipeline):
     campaign table (device hash probe) and counted in 10 s tumbling windows per campaign, all on the device."""
 
     def __init__(self, gpu_id=0, sources=8, batch=128 * 1024, period_us=1, delay_us=10_000_000, inflight=4, agg_replicas=1, transport=None,
-                 split_merge=False):
+                 split_merge=False, deterministic=False):
         ext = load_ext()
-        super().__init__(ext.YsbPipeline(gpu_id, sources, batch, period_us, delay_us, inflight, agg_replicas, transport, split_merge))
+        super().__init__(ext.YsbPipeline(gpu_id, sources, batch, period_us, delay_us, inflight, agg_replicas, transport, split_merge, deterministic))
         self.sources = sources
 
 
