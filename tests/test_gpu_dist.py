@@ -225,6 +225,49 @@ def test_win_agg_deterministic_across_ranks(ext, world):
     assert all(s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
 
 
+@pytest.mark.parametrize("world,dist,keys", [(2, 2, 5000), (3, 0, 64), (2, 1, 300)])
+def test_pane_combiner_in_front_of_the_exchange(ext, world, dist, keys):
+    """Pane_Combiner_GPU folds every batch per (key, pane) on the GPU that produced it; the exchange carries partial results and the
+    owner's Key_FFAT_GPU combines them: same windows, same sums as shipping the tuples - with fewer bytes on the links (zipf keys:
+    far fewer on the busiest one)."""
+    n_sources, per_source, win, slide, delay = 2, 200_000, 4096, 1024, 40 * 8192  # (the delay covers the lag the sources are allowed: 8 batches)
+
+    def run(combiner):
+        fabric = ext.LocalFabric(world)
+        stats, errors = [None] * world, []
+
+        def rank_main(r):
+            try:
+                pipe = ext.WinAggPipeline(0, n_sources, 8192, keys, win, slide, True, delay, 4, ext.local_transport(fabric, r), 2, dist, 1.3, True, False, False,
+                                          combiner)
+                pipe.step(per_source)
+                pipe.step(per_source)
+                pipe.close()
+                stats[r] = pipe.stats()
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=100)
+        assert not errors, errors
+        assert all(s is not None for s in stats)
+        return stats
+
+    plain, comb = run(False), run(True)
+    for stats in (plain, comb):
+        assert all(s["dropped"] == 0 and s["overflow"] == 0 and s["table_full"] == 0 for s in stats)
+    assert sum(s["sink_tuples"] for s in plain) == sum(s["sink_tuples"] for s in comb) > 0
+    assert sum(s["sink_value_sum"] for s in plain) == sum(s["sink_value_sum"] for s in comb)  # (integers in doubles: exact)
+    assert sum(s["combiner_tuples_in"] for s in comb) == world * n_sources * 2 * per_source
+    sent_plain, sent_comb = sum(s["exchange_tuples_sent"] for s in plain), sum(s["exchange_tuples_sent"] for s in comb)
+    assert sent_plain == world * n_sources * 2 * per_source and sent_comb < sent_plain
+    if dist == 2:  # zipf(1.3): the hot keys collapse to a partial per pane and batch
+        assert max(s["exchange_busiest_link_bytes"] for s in plain) > 3 * max(s["exchange_busiest_link_bytes"] for s in comb)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

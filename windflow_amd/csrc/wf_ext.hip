@@ -357,6 +357,13 @@ static void exchange_stats(py::dict& d, const ExchangeStats& x, size_t lanes) {
     d["exchange_tuples_sent"] = x.tuples_sent;
     d["exchange_tuples_received"] = x.tuples_received;
     d["exchange_max_link_bytes_per_round"] = x.max_link_bytes_per_round;
+    uint64_t busiest = 0, all_links = 0;
+    for (uint64_t b : x.link_bytes_sent) {
+        busiest = std::max(busiest, b);
+        all_links += b;
+    }
+    d["exchange_busiest_link_bytes"] = busiest;  // bytes this rank put on its busiest outgoing link over the whole run
+    d["exchange_link_bytes_total"] = all_links;
     d["exchange_rounds_per_s"] = x.elapsed_us ? (double)x.rounds * 1e6 / (double)x.elapsed_us : 0.0;
     d["exchange_lanes"] = lanes;
 }
@@ -417,7 +424,6 @@ public:
             source_ = BatchSource_Builder(gen).withName("source").withParallelism(n_sources).withBatch(batch_len).withInFlightBatches(inflight)
                           .withGPUConfiguration(gpu_id).build_unique();
         }
-        (void)combiner;
         MultiPipe& mp = graph_.add_source(*source_);
         KeyFFATGPUConfig wcfg;
         wcfg.win_len = win;
@@ -431,17 +437,36 @@ public:
         cfg.gpu_id = gpu_id;
         cfg.batch_len = batch_len;
         cfg.pool_slabs = inflight;
+        const bool use_combiner = combiner && transport && time_based;
+        if (combiner && !use_combiner) throw std::invalid_argument("WinAggPipeline: the combiner needs a transport and time-based windows");
         if (transport) {
             // the exchange delivers `lanes` key-disjoint streams (owner rank, then lane inside the rank, both from the key hash):
             // one aggregation replica per lane, no second partitioning pass behind the all-to-all
             n_sinks_ = agg_replicas ? agg_replicas : std::min<size_t>(n_sources, 4);
-            exchange_ = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
-                            .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
-            mp.add(*exchange_);
+            if (use_combiner) {
+                // fold every batch per (key, pane) where it is produced; the partial results travel instead of the tuples
+                combiner_ = PaneCombinerGPU_Builder(wfbench::LiftValue{}, wfbench::CombSum{}).withTBWindows(std::chrono::microseconds(win), std::chrono::microseconds(slide))
+                                .withName("pane_combiner").withParallelism(n_sources).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
+                mp.chain(*combiner_);
+                auto ex = ExchangeGPU_Builder<result_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
+                              .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
+                auto* raw = ex.get();
+                exchange_stats_ = [raw] { return raw->stats(); };
+                mp.add(*ex);
+                exchange_ = std::move(ex);
+            } else {
+                auto ex = ExchangeGPU_Builder<tuple_t>(transport).withName("exchange").withParallelism(n_sources).withLocalLanes(n_sources)
+                              .withOutputLanes(n_sinks_).withGPUConfiguration(gpu_id).withInFlightBatches(inflight).build_unique();
+                auto* raw = ex.get();
+                exchange_stats_ = [raw] { return raw->stats(); };
+                mp.add(*ex);
+                exchange_ = std::move(ex);
+            }
             wcfg.lanes_are_key_disjoint = true;
             // hash partitioning is only balanced on average: leave headroom in the per-replica key tables and in the
             // result batches (a lane receives what `world` ranks send it in a round)
-            wcfg.max_keys = n_keys * n_sources / n_sinks_;
+            // (shared keys: n_keys is the key space of the whole job, spread by hash over world x lanes replicas)
+            wcfg.max_keys = shared_keys ? (n_keys + world * n_sinks_ - 1) / (world * n_sinks_) : n_keys * n_sources / n_sinks_;
             wcfg.max_keys += wcfg.max_keys / 4 + 1024;
             // a round carries up to one batch per local lane and rank: the lane batches hold up to 2 * n_sources / lanes input batches
             wcfg.out_capacity = std::max<size_t>(2 * n_sources * batch_len / n_sinks_, batch_len);
@@ -456,8 +481,19 @@ public:
             if (n_sinks_ == 1) punct_expected_ = n_sources;  // no KeyBy in front of a single replica: it sees every lane's punctuation
         }
         if (punct_expected_ == 0) punct_expected_ = n_sinks_;
-        kff_.reset(new Key_FFAT_GPU<tuple_t, result_t>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg));
-        mp.add(*kff_);
+        if (use_combiner) {
+            auto k = std::make_unique<Key_FFAT_GPU<result_t, result_t>>(PartialLift<result_t>{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg);
+            auto* raw = k.get();
+            counters_ = [raw] { return raw->getDeviceCounters(); };
+            mp.add(*k);
+            kff_ = std::move(k);
+        } else {
+            auto k = std::make_unique<Key_FFAT_GPU<tuple_t, result_t>>(wfbench::LiftValue{}, wfbench::CombSum{}, wcfg, n_sinks_, "key_ffat_gpu", cfg);
+            auto* raw = k.get();
+            counters_ = [raw] { return raw->getDeviceCounters(); };
+            mp.add(*k);
+            kff_ = std::move(k);
+        }
         auto sink_f = [totals, barrier](const result_t* data, size_t n, const gpu::BatchHeader& h) {
             double s = 0.0;
             for (size_t i = 0; i < n; i++) s += data[i].value;
@@ -509,7 +545,7 @@ public:
         d["latency_samples"] = latency_->count();
         d["threads"] = graph_.getNumThreads();
         uint64_t dropped = 0, overflow = 0, skipped = 0, full = 0, huge = 0;
-        for (auto& c : kff_->getDeviceCounters()) {
+        for (auto& c : counters_()) {
             huge += c.huge_runs;
             dropped += c.dropped;
             overflow += c.overflow;
@@ -521,7 +557,8 @@ public:
         d["skipped_windows"] = skipped;
         d["table_full"] = full;
         d["huge_runs"] = huge;
-        if (exchange_) exchange_stats(d, exchange_->stats(), exchange_->getOutputLanes());
+        if (exchange_) exchange_stats(d, exchange_stats_(), n_sinks_);
+        if (combiner_) d["combiner_tuples_in"] = combiner_->tuples_in();
         return d;
     }
     void reset_latency() { latency_->clear(); }
@@ -536,9 +573,10 @@ private:
     std::shared_ptr<LatencyRecorder> latency_;
     gpu::DeviceBuffer<wfbench::KeySpace::Bucket> zipf_dev_;
     std::shared_ptr<std::vector<wfbench::KeySpace::Bucket>> zipf_host_;
-    std::unique_ptr<Basic_Operator> source_;
-    std::unique_ptr<Exchange_GPU<tuple_t>> exchange_;
-    std::unique_ptr<Key_FFAT_GPU<tuple_t, result_t>> kff_;
+    std::unique_ptr<Basic_Operator> source_, exchange_, kff_;
+    std::unique_ptr<Pane_Combiner_GPU<tuple_t, result_t>> combiner_;
+    std::function<ExchangeStats()> exchange_stats_;
+    std::function<std::vector<gpu::FFATCounters>()> counters_;
     std::unique_ptr<Batch_Sink<result_t>> sink_;
     uint64_t step_id_ = 0;
     bool closed_ = false;

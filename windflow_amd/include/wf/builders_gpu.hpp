@@ -7,6 +7,7 @@
 #pragma once
 #include "builders.hpp"
 #include "gpu/batch_ops.hpp"
+#include "gpu/combiner_gpu.hpp"
 #include "gpu/filter_gpu.hpp"
 #include "gpu/map_gpu.hpp"
 #include "gpu/key_ffat_gpu.hpp"
@@ -637,6 +638,29 @@ private:
     bool skip_gaps_ = false;
     bool disjoint_ = false;
     routing_func_t routing_ = default_routing;
+};
+
+// Pane_Combiner_GPU (gpu/combiner_gpu.hpp): lift + combine of a time-based keyed aggregation, applied per (key, pane) to every
+// batch where the tuples are produced; its partial results feed an Exchange_GPU and a Key_FFAT_GPU built with
+// KeyFFATGPU_Builder(PartialLift<result_t>(), comb)
+template <typename L, typename C>
+class PaneCombinerGPU_Builder : public GPU_Window_Builder_Base<PaneCombinerGPU_Builder<L, C>> {
+public:
+    using tuple_t = typename meta::lift_sig<L>::tuple_t;
+    using result_t = typename meta::lift_sig<L>::result_t;
+    using combiner_t = Pane_Combiner_GPU<tuple_t, result_t>;
+    PaneCombinerGPU_Builder(L lift, C comb) : GPU_Window_Builder_Base<PaneCombinerGPU_Builder<L, C>>("pane_combiner_gpu"), lift_(std::move(lift)), comb_(std::move(comb)) {
+        this->cfg_.batch_len = 65536;
+    }
+    combiner_t* build_ptr() {
+        if (this->type_ != TB) fatal_error("Pane_Combiner_GPU: only time-based windows have panes that several producers can fill independently");
+        return new combiner_t(lift_, comb_, this->win_, this->slide_, this->parallelism_, this->name_, this->cfg_, this->closing_);
+    }
+    std::unique_ptr<combiner_t> build_unique() { return std::unique_ptr<combiner_t>(build_ptr()); }
+
+private:
+    L lift_;
+    C comb_;
 };
 
 // sequential flavour: one replica (reference WinSeqFFATGPU_Builder, builders_gpu.hpp:195)

@@ -76,6 +76,7 @@ struct ExchangeStats {
     uint64_t lane_batches = 0;   // batches delivered downstream
     uint64_t tuples_sent = 0, tuples_received = 0, bytes_received = 0;
     uint64_t max_link_bytes_per_round = 0;  // xGMI is point to point: a round is bound by its busiest link
+    uint64_t link_bytes_sent[dist::MAX_WORLD] = {};  // bytes this rank has put on the link to every peer (the busiest one bounds the job)
     uint64_t start_us = 0, elapsed_us = 0;
 };
 
@@ -599,7 +600,10 @@ private:
                     sl.recv_bytes[p] = chunk[p] * sizeof(tuple_t);
                     off += chunk[p];
                 }
-                if (p != me) xstats_->max_link_bytes_per_round = std::max<uint64_t>(xstats_->max_link_bytes_per_round, std::max(sl.send_bytes[p], sl.recv_bytes[p]));
+                if (p != me) {
+                    xstats_->max_link_bytes_per_round = std::max<uint64_t>(xstats_->max_link_bytes_per_round, std::max(sl.send_bytes[p], sl.recv_bytes[p]));
+                    xstats_->link_bytes_sent[p] += sl.send_bytes[p];
+                }
             }
             xstats_->tuples_sent += sent;
             xstats_->tuples_received += total;
