@@ -160,8 +160,8 @@ int main(int argc, char** argv) {
     }
     std::atomic<uint64_t> generated{0}, results{0};
     if (batch_fed) {
-        if (op != "kf_gpu" && op != "wf_gpu" && op != "kff_gpu") {
-            std::cerr << "-B needs a flat GPU operator (kf_gpu, wf_gpu, kff_gpu)" << std::endl;
+        if (op != "kf_gpu" && op != "wf_gpu" && op != "kff_gpu" && op != "pf_gpu" && op != "wmr_gpu") {
+            std::cerr << "-B needs a GPU operator with a batch path (kf_gpu, wf_gpu, kff_gpu, pf_gpu, wmr_gpu)" << std::endl;
             return 2;
         }
         const size_t keys_per_source = std::max<size_t>(1, keys / sources);
@@ -180,6 +180,12 @@ int main(int argc, char** argv) {
                        .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
         else if (op == "wf_gpu")
             oper = WinFarmGPU_Builder(SumGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)
+                       .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        else if (op == "pf_gpu")  // both stages on the device: PLQ -> WLQ inside every replica
+            oper = PaneFarmGPU_Builder(SumGPU(), Sum2GPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas, replicas).withMaxKeys(max_keys)
+                       .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        else if (op == "wmr_gpu")  // every window cut into 4 stripes: map per stripe, reduce over the 4 partial results
+            oper = WinMapReduceGPU_Builder(SumGPU(), Sum2GPU()).withCBWindows(win, slide).withName(op).withParallelism(4, replicas).withMaxKeys(max_keys)
                        .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
         else
             oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)

@@ -4,7 +4,9 @@
 // (test_mp_gpu_{kf,wf,pf,wmr,kf+pf,wf+wmr,...}_{cb,tb}) plus Key_FFAT_GPU.
 //
 //   test_mp_windows_gpu -t <op> -m <cb|tb|tbd> [-r runs] [-l len] [-k keys] [-w win] [-s slide]
-//     op: seq kf wf pf_plq pf_wlq wmr_map wmr_red kff kf+pf wf+wmr
+//     op: seq kf wf pf_plq pf_wlq wmr_map wmr_red kff kf+pf wf+wmr kf+wmr wf+pf (one stage on the CPU, as in the reference)
+//         pf_gg wmr_gg kf+pf_gg wf+pf_gg kf+wmr_gg wf+wmr_gg             (both stages on the device: batch path)
+//     -c: "chaining" variant (src/mp_test_gpu/test_mp_gpu_*_chaining.cpp): equal parallelism everywhere, every operator chain()ed
 #include <unistd.h>
 
 #include <chrono>
@@ -46,6 +48,7 @@ struct Cfg {
     string op = "kf", mode = "cb";
     size_t runs = 3, len = 2000, keys = 4;
     uint64_t win = 10, slide = 3;
+    bool chaining = false;
 };
 
 template <typename B>
@@ -68,7 +71,8 @@ static B& set_nic_windows(B& b, const Cfg& c) {
 static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector<shared_ptr<Basic_Operator>>& keep, string& descr) {
     std::uniform_int_distribution<int> d(1, 4);
     std::uniform_int_distribution<int> db(1, 300);
-    const size_t p1 = (size_t)d(rng), p2 = (size_t)d(rng), p3 = (size_t)d(rng);
+    size_t p1 = (size_t)d(rng), p2 = (size_t)d(rng), p3 = (size_t)d(rng);
+    if (c.chaining) p1 = p2 = p3 = 2;
     const size_t batch = (size_t)db(rng);
     auto hold = [&keep](auto* op) {
         keep.emplace_back(op);
@@ -117,6 +121,34 @@ static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector
         auto b = WinMapReduceGPU_Builder(win_nic, Win2_GPU());
         auto* wmr = hold(set_nic_windows(b, c).withName("wmr_inner").withParallelism(p2 + 1, p3).withBatch(batch).prepare4Nesting().build_ptr());
         mp.add(*hold(WinFarmGPU_Builder(*wmr).withName("wf_wmr_gpu").withParallelism(p1).build_ptr()));
+    } else if (c.op == "kf+wmr") {
+        auto b = WinMapReduceGPU_Builder(Win_GPU(), win2_nic);
+        auto* wmr = hold(set_nic_windows(b, c).withName("wmr_inner").withParallelism(p2 + 1, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        mp.add(*hold(KeyFarmGPU_Builder(*wmr).withName("kf_wmr_gpu").withParallelism(p1).build_ptr()));
+    } else if (c.op == "wf+pf") {
+        auto b = PaneFarmGPU_Builder(win_nic, Win2_GPU());
+        auto* pf = hold(set_nic_windows(b, c).withName("pf_inner").withParallelism(p2, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        mp.add(*hold(WinFarmGPU_Builder(*pf).withName("wf_pf_gpu").withParallelism(p1).build_ptr()));
+    } else if (c.op == "pf_gg") {  // both stages on the device: replicas divide the keys, PLQ -> WLQ without leaving HBM
+        auto b = PaneFarmGPU_Builder(Win_GPU(), Win2_GPU());
+        mp.add(*hold(set_nic_windows(b, c).withName("pf_gg").withParallelism(p1, p2).withBatch(batch).withScratchpad(16).build_ptr()));
+    } else if (c.op == "wmr_gg") {
+        auto b = WinMapReduceGPU_Builder(Win_GPU(), Win2_GPU());
+        mp.add(*hold(set_nic_windows(b, c).withName("wmr_gg").withParallelism(p1 + 1, p2).withBatch(batch).build_ptr()));
+    } else if (c.op == "kf+pf_gg" || c.op == "wf+pf_gg") {
+        auto b = PaneFarmGPU_Builder(Win_GPU(), Win2_GPU());
+        auto* pf = hold(set_nic_windows(b, c).withName("pf_inner").withParallelism(p2, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        if (c.op[0] == 'k')
+            mp.add(*hold(KeyFarmGPU_Builder(*pf).withName("kf_pf_gg").withParallelism(p1).build_ptr()));
+        else
+            mp.add(*hold(WinFarmGPU_Builder(*pf).withName("wf_pf_gg").withParallelism(p1).build_ptr()));
+    } else if (c.op == "kf+wmr_gg" || c.op == "wf+wmr_gg") {
+        auto b = WinMapReduceGPU_Builder(Win_GPU(), Win2_GPU());
+        auto* wmr = hold(set_nic_windows(b, c).withName("wmr_inner").withParallelism(p2 + 1, p3).withBatch(batch).prepare4Nesting().build_ptr());
+        if (c.op[0] == 'k')
+            mp.add(*hold(KeyFarmGPU_Builder(*wmr).withName("kf_wmr_gg").withParallelism(p1).build_ptr()));
+        else
+            mp.add(*hold(WinFarmGPU_Builder(*wmr).withName("wf_wmr_gg").withParallelism(p1).build_ptr()));
     } else {
         cerr << "unknown operator " << c.op << endl;
         exit(2);
@@ -126,7 +158,7 @@ static void add_window_op(MultiPipe& mp, const Cfg& c, std::mt19937& rng, vector
 int main(int argc, char* argv[]) {
     Cfg c;
     int o;
-    while ((o = getopt(argc, argv, "t:m:r:l:k:w:s:")) != -1) {
+    while ((o = getopt(argc, argv, "t:m:r:l:k:w:s:c")) != -1) {
         switch (o) {
             case 't': c.op = optarg; break;
             case 'm': c.mode = optarg; break;
@@ -135,6 +167,7 @@ int main(int argc, char* argv[]) {
             case 'k': c.keys = (size_t)atoi(optarg); break;
             case 'w': c.win = (uint64_t)atoll(optarg); break;
             case 's': c.slide = (uint64_t)atoll(optarg); break;
+            case 'c': c.chaining = true; break;
             default: return 2;
         }
     }
@@ -149,7 +182,8 @@ int main(int argc, char* argv[]) {
     std::uniform_int_distribution<int> d(1, 4);
     int failures = 0;
     for (size_t run = 0; run < c.runs; run++) {
-        const size_t fp = (size_t)d(rng), mpp = (size_t)d(rng);
+        size_t fp = (size_t)d(rng), mpp = (size_t)d(rng);
+        if (c.chaining) fp = mpp = 2;  // equal parallelism: chain() really fuses the CPU operators
         SinkTotals totals;
         PipeGraph graph("test_mp_gpu_" + c.op + "_" + c.mode, c.mode == "tbd" ? Mode::DEFAULT : Mode::DETERMINISTIC);
         Source source = Source_Builder(Source_Functor(c.len, c.keys)).withName("source").withParallelism(1).build();
@@ -165,6 +199,7 @@ int main(int argc, char* argv[]) {
         add_window_op(mp, c, rng, keep, descr);
         Sink sink = Sink_Builder(Sink_Functor(&totals)).withName("sink").withParallelism(1).build();
         mp.chain_sink(sink);
+        if (c.chaining) descr += " chaining, " + to_string(graph.getNumThreads()) + " threads";
         graph.run();
         bool ok = totals.received == expect.windows;
         if (c.mode != "tbd") ok = ok && totals.sum == expect.sum;

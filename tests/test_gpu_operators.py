@@ -21,7 +21,9 @@ def run_gpu_cpp(args, timeout=110):
     return r.stdout
 
 
-GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "seqffat", "kf+pf", "wf+wmr"]
+# one stage of the two-stage operators on the CPU (the reference's matrix, incl. all four nestings), then both on the device
+GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "seqffat", "kf+pf", "wf+wmr", "kf+wmr", "wf+pf",
+           "pf_gg", "wmr_gg", "kf+pf_gg", "wf+pf_gg", "kf+wmr_gg", "wf+wmr_gg"]
 
 
 @pytest.mark.parametrize("op", GPU_OPS)
@@ -32,10 +34,29 @@ def test_gpu_window_operators(op, mode):
     assert out.count("  OK") == 2 and "FAILED" not in out
 
 
-@pytest.mark.parametrize("op", ["kf", "wf", "kff"])
+@pytest.mark.parametrize("op", ["kf", "wf", "kff", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "pf_gg", "wmr_gg", "kf+pf_gg", "wf+wmr_gg"])
 def test_gpu_window_operators_default_mode(op):
     out = run_gpu_cpp(["-t", op, "-m", "tbd", "-r", 2, "-l", 1000, "-k", 4, "-w", "900", "-s", "300"])
     assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+@pytest.mark.parametrize("op", ["kf", "wf", "pf_plq", "wmr_red", "kff", "pf_gg", "wmr_gg", "kf+pf_gg"])
+@pytest.mark.parametrize("mode", ["cb", "tb"])
+def test_gpu_window_operators_chaining(op, mode):
+    """reference: src/mp_test_gpu/test_mp_gpu_*_chaining.cpp - equal parallelism, every operator chained"""
+    win, slide = ("14", "4") if mode == "cb" else ("1000", "300")
+    out = run_gpu_cpp(["-t", op, "-m", mode, "-r", 2, "-l", 1200, "-k", 5, "-w", win, "-s", slide, "-c"])
+    assert out.count("  OK") == 2 and "FAILED" not in out and "chaining" in out
+
+
+def test_gpu_window_operators_tuple_path_still_works():
+    """WF_TUPLE_PATH=1: GPU operators behind CPU producers are fed tuple by tuple (no batchers), as in the reference"""
+    for op in ("kf", "wf", "kff", "pf_gg"):
+        exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_mp_windows_gpu.hip"), os.path.join(BIN, "test_mp_windows_gpu"), hip=True,
+                                extra=["-I" + os.path.join(HERE, "cpp")])
+        r = subprocess.run([exe, "-t", op, "-m", "cb", "-r", "1", "-l", "800", "-k", "5", "-w", "14", "-s", "4"], capture_output=True, text=True, timeout=110,
+                           env=dict(os.environ, WF_QUIET="1", WF_TUPLE_PATH="1"))
+        assert r.returncode == 0 and "  OK" in r.stdout, op + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def run_keyed_cpp(args, timeout=110, env=None):

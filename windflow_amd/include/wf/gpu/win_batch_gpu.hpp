@@ -65,6 +65,28 @@ struct is_wave_reduce_t : std::false_type {};
 template <typename F>
 struct is_wave_reduce_t<F, std::void_t<decltype(F::is_wave_reduce)>> : std::true_type {};
 
+// ---- map + reduce over one window (Win_MapReduce_GPU on batches) ---------------------------------
+// map_reduce(map, reduce, M): the window is cut into M stripes (the tuples at window positions m, m + M, m + 2M ... form
+// stripe m - on the CPU the tuples of a key are dealt round-robin to M MAP replicas, /root/reference/wf/wm_nodes.hpp:126-134),
+// `map` computes a partial result per stripe and `reduce` the window's result from the M partials; both are device functors
+// with the 6-argument signature.  One workgroup per window: its 256 threads lay the window out stripe by stripe in a scratch
+// area, M of them run `map`, one runs `reduce`.
+template <typename MapF, typename RedF>
+struct MapReduceFunc {
+    static constexpr bool is_map_reduce = true;
+    MapF map;
+    RedF red;
+    uint32_t stripes;
+};
+template <typename MapF, typename RedF>
+inline MapReduceFunc<MapF, RedF> map_reduce(MapF map, RedF red, size_t stripes) {
+    return MapReduceFunc<MapF, RedF>{map, red, (uint32_t)(stripes < 1 ? 1 : stripes)};
+}
+template <typename F, typename = void>
+struct is_map_reduce_t : std::false_type {};
+template <typename F>
+struct is_map_reduce_t<F, std::void_t<decltype(F::is_map_reduce)>> : std::true_type {};
+
 // ---- parameters -----------------------------------------------------------------------------
 struct WinGeometry {
     uint64_t win, slide, delay;
@@ -658,6 +680,52 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// map + reduce evaluation (see MapReduceFunc): one workgroup per window.  `area`: per-workgroup scratch of `area_tuples` tuples;
+// a window that does not fit is evaluated as a single stripe straight from the work buffer (any partition of the window is a
+// legal one).  `partials`: per-workgroup array of `stripes` results.
+template <typename T, typename R, typename MapF, typename RedF>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    wb_eval_mapreduce_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, T* area, uint32_t area_tuples, R* partials,
+                             uint32_t stripes, char* scratch, size_t scratch_size, MapF map, RedF red) {
+    uint32_t n_win = ctl->win_total;
+    if (n_win > out_cap) n_win = out_cap;
+    T* my_area = area + (size_t)blockIdx.x * area_tuples;
+    R* my_part = partials + (size_t)blockIdx.x * stripes;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    char* my_scratch = scratch_size ? scratch + (size_t)tid * scratch_size : nullptr;
+    for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {
+        const WinDesc d = desc[w];
+        const T* src = base + d.off;
+        const uint32_t len = d.len;
+        const uint32_t M = len <= area_tuples ? stripes : 1u;
+        const uint32_t q = len / M, rem = len % M;  // stripe m holds q tuples, one more when m < rem
+        if (M > 1)
+            for (uint32_t p = threadIdx.x; p < len; p += BLOCK_THREADS) {
+                const uint32_t m = p % M;
+                my_area[(size_t)m * q + (m < rem ? m : rem) + p / M] = src[p];
+            }
+        __syncthreads();
+        const R stamped = out[w];
+        if (threadIdx.x < M) {
+            const uint32_t m = threadIdx.x;
+            R part{};
+            part.setControlFields(cf_key(stamped), (uint64_t)m, cf_ts(stamped));
+            const T* stripe = M > 1 ? my_area + (size_t)m * q + (m < rem ? m : rem) : src;
+            map(d.gwid, stripe, (size_t)(q + (m < rem ? 1u : 0u)), &part, my_scratch, scratch_size);
+            part.setControlFields(cf_key(stamped), (uint64_t)m, cf_ts(stamped));
+            my_part[m] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            R res = stamped;
+            red(d.gwid, static_cast<const R*>(my_part), (size_t)M, &res, my_scratch, scratch_size);
+            res.setControlFields(cf_key(stamped), cf_id(stamped), cf_ts(stamped));
+            out[w] = res;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- 8. carry + state --------------------------------------------------------------------------------
 // A run's carry (the tail of its segment that open windows still need) is copied by `chunks` waves, WB_COMMIT_CHUNK words
 // each, so that a few long carries (few keys, long windows) spread over the whole chip; wave 0 of a run writes its state.
@@ -848,6 +916,17 @@ public:
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(WinCounters), init.get()));
         if (scratch_size_ > 0) scratch_.resize((size_t)EVAL_GRID * BLOCK_THREADS * scratch_size_);
+        if constexpr (is_map_reduce_t<F>::value) {
+            if (func_.stripes > BLOCK_THREADS) failwith("Win_MapReduce_GPU: at most 256 map stripes per window");
+            // scratch of a workgroup: a whole window (count-based), or what a key can hold between two batches plus a batch (time-based)
+            size_t longest = g_.is_tb ? (size_t)g_.carry_cap + batch_cap_ : (size_t)std::min<uint64_t>(g_.win, (uint64_t)g_.carry_cap + batch_cap_);
+            mr_grid_ = EVAL_GRID;
+            while (mr_grid_ > 64 && (size_t)mr_grid_ * longest * sizeof(T) > (2ull << 30)) mr_grid_ /= 2;
+            while ((size_t)mr_grid_ * longest * sizeof(T) > (2ull << 30) && longest > 1024) longest /= 2;  // (longer windows: one stripe, see the kernel)
+            mr_area_tuples_ = (uint32_t)longest;
+            mr_area_.resize((size_t)mr_grid_ * longest);
+            mr_partials_.resize((size_t)mr_grid_ * func_.stripes);
+        }
         // windows per workgroup of the LDS-tiled evaluation: as many consecutive windows as share one 64 KB tile (0: a window
         // alone does not fit, evaluate from global memory).  Time-based windows are sized as if a key ticked once per time unit,
         // bounded by what a key can carry; a group that turns out larger than the tile falls back to global memory by itself.
@@ -982,7 +1061,11 @@ private:
         // at most out_cap windows are described and evaluated; the grid-stride loops read the exact count on the device
         hipLaunchKernelGGL((wb_desc_kernel<T, R>), dim3(grid_for(g_.out_cap)), dim3(BLOCK_THREADS), 0, s, table_.data(), states_.data(), runs_.data(),
                            win_off_.data(), n_fire_.data(), base, desc_.data(), out->template data<R>(), ctl_.data(), g_, flushing);
-        if constexpr (is_wave_reduce_t<F>::value) {
+        if constexpr (is_map_reduce_t<F>::value) {
+            hipLaunchKernelGGL((wb_eval_mapreduce_kernel<T, R, decltype(func_.map), decltype(func_.red)>), dim3(mr_grid_), dim3(BLOCK_THREADS), 0, s, base,
+                               desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, mr_area_.data(), mr_area_tuples_, mr_partials_.data(),
+                               func_.stripes, scratch_.data(), scratch_size_, func_.map, func_.red);
+        } else if constexpr (is_wave_reduce_t<F>::value) {
             hipLaunchKernelGGL((wb_eval_reduce_kernel<T, R, decltype(func_.lift), decltype(func_.comb)>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base,
                                desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, func_.lift, func_.comb);
         } else if (tile_group_ > 0) {
@@ -1017,6 +1100,10 @@ private:
     DeviceBuffer<WinCtl> ctl_;
     DeviceBuffer<WinCounters> counters_;
     DeviceBuffer<char> scratch_;
+    DeviceBuffer<T> mr_area_;      // map + reduce evaluation: per-workgroup window laid out stripe by stripe
+    DeviceBuffer<R> mr_partials_;
+    unsigned mr_grid_ = 0;
+    uint32_t mr_area_tuples_ = 0;
     RadixSorter sorter_;
     std::unique_ptr<BatchPool> out_pool_;
 };

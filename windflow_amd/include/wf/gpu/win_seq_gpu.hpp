@@ -125,6 +125,253 @@ inline typename GPU_Keyed_Window_Stage<tuple_t, result_t>::node_factory_t gpu_wi
     };
 }
 
+#define WF_COMMA ,
+// which of the two stage functions are device functors (6 arguments, or wave_reduce)
+namespace meta {
+template <typename F>
+constexpr bool is_gpu_stage_func() {
+    if constexpr (gpu::is_wave_reduce_t<F>::value)
+        return true;
+    else
+        return is_gpu_win_func<F>();
+}
+}  // namespace meta
+
+// ---- both stages of a pane farm on the device (batch path) ----------------------------------------------------------
+// One replica = two engines on one stream: the PLQ engine turns a batch of tuples into the batch of the panes it completes
+// (tumbling windows of gcd(win, slide), role PLQ: results numbered per key), the WLQ engine consumes that device batch and
+// fires the windows (count-based windows of win / pane pane results sliding by slide / pane, role WLQ).  Pane results never
+// leave HBM.  (The reference needs exactly one of the two functions on the host: wf/pane_farm_gpu.hpp:124-548.)
+template <typename tuple_t, typename result_t, typename F1, typename F2>
+class PaneFarmBatchGPU_Node : public GPU_Replica<tuple_t> {
+public:
+    PaneFarmBatchGPU_Node(F1 plq, F2 wlq, WinParams p, gpu::WinGPUOptions opt, GPUConfig cfg, edge_kind_t in_kind, std::string name, size_t par, size_t idx,
+                          meta::closing_func_t closing, std::shared_ptr<StatsHub> hub, std::shared_ptr<std::vector<gpu::WinCounters>> counters)
+        : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub), true), plq_f_(plq), wlq_f_(wlq), p_(p), opt_(opt),
+          counters_(std::move(counters)) {
+        if (p_.win_len == 0 || p_.slide_len == 0) fatal_error("window length or slide cannot be zero");
+    }
+
+protected:
+    void process_device(gpu::Batch* d) override {
+        ensure_engines(d->capacity);
+        hipStream_t s = this->stream();
+        gpu::Batch* panes = plq_->process(d, s, this->num_kernels_);
+        this->release_input(d);
+        gpu::Batch* out = wlq_->process(panes, s, this->num_kernels_);
+        panes->release(s);
+        this->emit_device(out);
+        if (++since_check_ >= 256) {
+            since_check_ = 0;
+            check(plq_->read_counters(s), "PLQ");
+            check(wlq_->read_counters(s), "WLQ");
+        }
+    }
+    void gpu_flush() override {
+        if (!plq_) return;
+        hipStream_t s = this->stream();
+        size_t cursor = 0;
+        gpu::Batch* panes = nullptr;
+        while (plq_->flush_range(cursor, s, this->num_kernels_, panes)) {
+            gpu::Batch* out = wlq_->process(panes, s, this->num_kernels_);
+            panes->release(s);
+            this->emit_device(out);
+        }
+        cursor = 0;
+        gpu::Batch* out = nullptr;
+        while (wlq_->flush_range(cursor, s, this->num_kernels_, out)) this->emit_device(out);
+        const gpu::WinCounters c1 = plq_->read_counters(s), c2 = wlq_->read_counters(s);
+        if (counters_) (*counters_)[this->context.getReplicaIndex()] = c1;
+        dropped_ = c1.dropped;
+        check(c1, "PLQ");
+        check(c2, "WLQ");
+    }
+    void finalize_stats(Stats_Record& st) override {
+        GPU_Replica<tuple_t>::finalize_stats(st);
+        st.inputs_ignored = dropped_;
+    }
+
+private:
+    void ensure_engines(size_t batch_capacity) {
+        if (plq_) return;
+        const uint64_t pane = std::gcd(p_.win_len, p_.slide_len);
+        WinParams p1 = p_;
+        p1.win_len = pane;
+        p1.slide_len = pane;
+        p1.config = WinOperatorConfig(0, 1, pane, 0, 1, pane);
+        p1.role = PLQ;
+        gpu::WinGPUOptions o1 = opt_;
+        o1.out_capacity = 0;  // panes per batch: the engine's default (twice the input batch), the rest is deferred
+        if (p_.winType == TB && o1.carry_capacity == 0) o1.carry_capacity = 1024;
+        plq_.reset(new gpu::WinBatchEngine<tuple_t, result_t, F1>(plq_f_, p1, o1, batch_capacity, this->cfg_.gpu_id, this->cfg_.pool_slabs, this->cfg_.scratchpad_size));
+        WinParams p2;
+        p2.win_len = p_.win_len / pane;
+        p2.slide_len = p_.slide_len / pane;
+        p2.triggering_delay = 0;
+        p2.winType = CB;
+        p2.config = WinOperatorConfig(0, 1, p2.slide_len, 0, 1, p2.slide_len);
+        p2.role = WLQ;
+        gpu::WinGPUOptions o2 = opt_;
+        o2.renumber = false;     // the ids of the pane results ARE the pane numbers
+        o2.carry_capacity = 0;   // count-based: the window length
+        o2.expect_disorder = false;
+        wlq_.reset(new gpu::WinBatchEngine<result_t, result_t, F2>(wlq_f_, p2, o2, plq_->geometry().out_cap, this->cfg_.gpu_id, this->cfg_.pool_slabs,
+                                                                  this->cfg_.scratchpad_size));
+    }
+    void check(const gpu::WinCounters& c, const char* stage) {
+        if (c.table_full > 0)
+            fatal_error(std::string("Pane_Farm_GPU (") + stage + "): tuples without a state slot - more keys than withMaxKeys(), or the reserved key 2^64-1");
+        if (c.carry_overflow > 0)
+            fatal_error(std::string("Pane_Farm_GPU (") + stage + "): " + std::to_string(c.carry_overflow) +
+                        " tuples needed by open windows did not fit their key's archive; raise withArchiveCapacity()");
+        if (c.work_overflow > 0) fatal_error(std::string("Pane_Farm_GPU (") + stage + "): work buffer overflow (internal sizing error)");
+    }
+    F1 plq_f_;
+    F2 wlq_f_;
+    WinParams p_;
+    gpu::WinGPUOptions opt_;
+    std::shared_ptr<std::vector<gpu::WinCounters>> counters_;
+    std::unique_ptr<gpu::WinBatchEngine<tuple_t, result_t, F1>> plq_;
+    std::unique_ptr<gpu::WinBatchEngine<result_t, result_t, F2>> wlq_;
+    uint64_t dropped_ = 0;
+    uint32_t since_check_ = 0;
+};
+
+// Base of the two-stage GPU operators: what Key_Farm_GPU / Win_Farm_GPU need to replicate their batch path
+template <typename tuple_t, typename result_t>
+class TwoStage_GPU_Mixin {
+public:
+    virtual ~TwoStage_GPU_Mixin() = default;
+    // both stage functions run on the device: the operator has a batch path (replicas divide the keys, each runs both stages)
+    bool has_batch_path() const { return (bool)batch_factory_; }
+    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> make_flat_stage(size_t replicas, const std::string& name, routing_func_t routing) const {
+        return std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>>(new GPU_Keyed_Window_Stage<tuple_t, result_t>(
+            batch_factory_, bwin_, bslide_, bdelay_, btype_, replicas, name, bcfg_, bopt_, std::move(routing)));
+    }
+    std::shared_ptr<std::vector<gpu::WinCounters>> batch_counters(size_t replicas) {
+        bcounters_->resize(std::max(bcounters_->size(), replicas));
+        return bcounters_;
+    }
+
+protected:
+    typename GPU_Keyed_Window_Stage<tuple_t, result_t>::node_factory_t batch_factory_;
+    uint64_t bwin_ = 0, bslide_ = 0, bdelay_ = 0;
+    win_type_t btype_ = CB;
+    GPUConfig bcfg_;
+    gpu::WinGPUOptions bopt_;
+    std::shared_ptr<std::vector<gpu::WinCounters>> bcounters_ = std::make_shared<std::vector<gpu::WinCounters>>();
+};
+
+// members shared by the two flat two-stage GPU operators (edge negotiation of the batch path)
+#define WF_TWO_STAGE_GPU_BATCH_PATH(BASE)                                                                                                       \
+    bool isGPUOperator() const override { return true; }                                                                                        \
+    bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }                                               \
+    bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }                                               \
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }       \
+    edge_kind_t output_kind() const override { return batch_path() ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }                                          \
+    bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }                                            \
+    void set_input_kind(edge_kind_t k) override {                                                                                               \
+        if (flat_) flat_->kind = k;                                                                                                             \
+    }                                                                                                                                           \
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {                                                             \
+        return batch_path() ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;                                                        \
+    }                                                                                                                                           \
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override {                                                                        \
+        return batch_path() ? flat_->build(g, this->hub_, m == Mode::DETERMINISTIC) : BASE::build_stages(g, m);                                 \
+    }                                                                                                                                           \
+    std::vector<gpu::WinCounters> getDeviceCounters() const { return *this->bcounters_; }                                                       \
+                                                                                                                                                \
+private:                                                                                                                                        \
+    bool batch_path() const { return flat_ && flat_->kind != EDGE_TUPLE; }                                                                      \
+    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_;
+
+template <typename tuple_t, typename result_t>
+class Pane_Farm_GPU : public Pane_Farm<tuple_t, result_t>, public TwoStage_GPU_Mixin<tuple_t, result_t> {
+public:
+    template <typename plq_t, typename wlq_t>
+    Pane_Farm_GPU(plq_t plq, wlq_t wlq, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type, size_t plq_parallelism,
+                  size_t wlq_parallelism, std::string name, GPUConfig cfg, meta::closing_func_t closing = nullptr, bool ordered = true,
+                  opt_level_t opt_level = LEVEL0, gpu::WinGPUOptions opt = gpu::WinGPUOptions())
+        : Pane_Farm<tuple_t, result_t>(typename Pane_Farm<tuple_t, result_t>::engines_tag{}, nullptr, nullptr, win_len, slide_len,
+                                       triggering_delay, type, plq_parallelism, wlq_parallelism, name, ordered, opt_level) {
+        constexpr bool gpu_plq = meta::is_gpu_stage_func<plq_t>();
+        constexpr bool gpu_wlq = meta::is_gpu_stage_func<wlq_t>();
+        static_assert(gpu_plq || gpu_wlq, "WindFlow Compilation Error - Pane_Farm_GPU: at least one of PLQ and WLQ must be a device functor");
+        win_engine_maker_t m1, m2;
+        if constexpr (gpu_plq)
+            m1 = gpu_win_engine<tuple_t, result_t>(plq, cfg, opt, closing, this->hub_);
+        else
+            m1 = cpu_win_engine<tuple_t, result_t>(plq, closing, this->hub_);
+        if constexpr (gpu_wlq)
+            m2 = gpu_win_engine<result_t, result_t>(wlq, cfg, opt, closing, this->hub_);
+        else
+            m2 = cpu_win_engine<result_t, result_t>(wlq, closing, this->hub_);
+        this->set_engines(std::move(m1), std::move(m2));
+        if constexpr (gpu_plq && gpu_wlq) {
+            // both functions on the device: fed by batches (or by tuple producers through their batchers) the replicas divide the
+            // keys and each runs PLQ and WLQ back to back on its stream
+            this->bwin_ = win_len;
+            this->bslide_ = slide_len;
+            this->bdelay_ = triggering_delay;
+            this->btype_ = type;
+            this->bcfg_ = cfg;
+            this->bopt_ = opt;
+            auto hub = this->hub_;
+            auto counters = this->bcounters_;
+            this->batch_factory_ = [=](const WinParams& p, const gpu::WinGPUOptions& o, edge_kind_t kind, size_t par, size_t idx) -> rt::Node* {
+                if (counters->size() < par) counters->resize(par);
+                return new PaneFarmBatchGPU_Node<tuple_t, result_t, plq_t, wlq_t>(plq, wlq, p, o, cfg, kind, name, par, idx, closing, hub, counters);
+            };
+            flat_ = this->make_flat_stage(std::max(plq_parallelism, wlq_parallelism), name, default_routing);
+        }
+    }
+    WF_TWO_STAGE_GPU_BATCH_PATH(Pane_Farm<tuple_t WF_COMMA result_t>)
+};
+
+template <typename tuple_t, typename result_t>
+class Win_MapReduce_GPU : public Win_MapReduce<tuple_t, result_t>, public TwoStage_GPU_Mixin<tuple_t, result_t> {
+public:
+    template <typename map_t, typename reduce_t>
+    Win_MapReduce_GPU(map_t map, reduce_t reduce, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
+                      size_t map_parallelism, size_t reduce_parallelism, std::string name, GPUConfig cfg, meta::closing_func_t closing = nullptr,
+                      bool ordered = true, opt_level_t opt_level = LEVEL0, gpu::WinGPUOptions opt = gpu::WinGPUOptions())
+        : Win_MapReduce<tuple_t, result_t>(typename Win_MapReduce<tuple_t, result_t>::engines_tag{}, nullptr, nullptr, win_len, slide_len,
+                                           triggering_delay, type, map_parallelism, reduce_parallelism, name, ordered, opt_level) {
+        constexpr bool gpu_map = meta::is_gpu_stage_func<map_t>();
+        constexpr bool gpu_red = meta::is_gpu_stage_func<reduce_t>();
+        static_assert(gpu_map || gpu_red, "WindFlow Compilation Error - Win_MapReduce_GPU: at least one of MAP and REDUCE must be a device functor");
+        win_engine_maker_t m1, m2;
+        if constexpr (gpu_map)
+            m1 = gpu_win_engine<tuple_t, result_t>(map, cfg, opt, closing, this->hub_);
+        else
+            m1 = cpu_win_engine<tuple_t, result_t>(map, closing, this->hub_);
+        if constexpr (gpu_red)
+            m2 = gpu_win_engine<result_t, result_t>(reduce, cfg, opt, closing, this->hub_);
+        else
+            m2 = cpu_win_engine<result_t, result_t>(reduce, closing, this->hub_);
+        this->set_engines(std::move(m1), std::move(m2));
+        if constexpr (gpu_map && gpu_red && !gpu::is_wave_reduce_t<map_t>::value && !gpu::is_wave_reduce_t<reduce_t>::value) {
+            // both functions on the device: every window is cut into map_parallelism stripes inside the engine (gpu::map_reduce)
+            this->bwin_ = win_len;
+            this->bslide_ = slide_len;
+            this->bdelay_ = triggering_delay;
+            this->btype_ = type;
+            this->bcfg_ = cfg;
+            this->bopt_ = opt;
+            auto hub = this->hub_;
+            auto counters = this->bcounters_;
+            const auto mr = gpu::map_reduce(map, reduce, map_parallelism);
+            using mr_t = std::decay_t<decltype(mr)>;
+            this->batch_factory_ = [=](const WinParams& p, const gpu::WinGPUOptions& o, edge_kind_t kind, size_t par, size_t idx) -> rt::Node* {
+                if (counters->size() < par) counters->resize(par);
+                return new WinBatchGPU_Node<tuple_t, result_t, mr_t>(mr, p, o, cfg, kind, name, par, idx, closing, hub, counters);
+            };
+            flat_ = this->make_flat_stage(reduce_parallelism, name, default_routing);
+        }
+    }
+    WF_TWO_STAGE_GPU_BATCH_PATH(Win_MapReduce<tuple_t WF_COMMA result_t>)
+};
+
 // ---- operators -------------------------------------------------------------------
 template <typename tuple_t, typename result_t>
 class Key_Farm_GPU : public Key_Farm<tuple_t, result_t> {
@@ -145,7 +392,14 @@ public:
     Key_Farm_GPU(TwoStage_Operator<tuple_t, result_t>& inner, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
                  size_t num_replicas, std::string name, meta::closing_func_t closing = nullptr, routing_func_t routing = default_routing,
                  opt_level_t opt_level = LEVEL2)
-        : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, std::move(routing), opt_level) {}
+        : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, name, closing, routing, opt_level) {
+        // an inner operator whose two stages both run on the device has a batch path: the outer replicas then divide the keys and
+        // each runs the inner operator's stages on its stream
+        if (auto* two = dynamic_cast<TwoStage_GPU_Mixin<tuple_t, result_t>*>(&inner); two != nullptr && two->has_batch_path()) {
+            counters_ = two->batch_counters(num_replicas);
+            flat_ = two->make_flat_stage(num_replicas, name, routing);
+        }
+    }
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
     bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }
@@ -196,7 +450,12 @@ public:
     }
     Win_Farm_GPU(TwoStage_Operator<tuple_t, result_t>& inner, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
                  size_t num_replicas, std::string name, meta::closing_func_t closing = nullptr, bool ordered = true, opt_level_t opt_level = LEVEL2)
-        : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, std::move(name), closing, ordered, opt_level) {}
+        : base_t(inner, win_len, slide_len, triggering_delay, type, num_replicas, name, closing, ordered, opt_level) {
+        if (auto* two = dynamic_cast<TwoStage_GPU_Mixin<tuple_t, result_t>*>(&inner); two != nullptr && two->has_batch_path()) {
+            counters_ = two->batch_counters(num_replicas);
+            flat_ = two->make_flat_stage(num_replicas, name, default_routing);
+        }
+    }
     bool isGPUOperator() const override { return true; }
     bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }
     bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }
@@ -216,67 +475,6 @@ private:
     bool batch_path() const { return flat_ && flat_->kind != EDGE_TUPLE; }
     std::shared_ptr<std::vector<gpu::WinCounters>> counters_;
     std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_;
-};
-
-// exactly one of the two stage functions is a device functor (6 arguments, or wave_reduce)
-namespace meta {
-template <typename F>
-constexpr bool is_gpu_stage_func() {
-    if constexpr (gpu::is_wave_reduce_t<F>::value)
-        return true;
-    else
-        return is_gpu_win_func<F>();
-}
-}  // namespace meta
-
-template <typename tuple_t, typename result_t>
-class Pane_Farm_GPU : public Pane_Farm<tuple_t, result_t> {
-public:
-    template <typename plq_t, typename wlq_t>
-    Pane_Farm_GPU(plq_t plq, wlq_t wlq, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type, size_t plq_parallelism,
-                  size_t wlq_parallelism, std::string name, GPUConfig cfg, meta::closing_func_t closing = nullptr, bool ordered = true,
-                  opt_level_t opt_level = LEVEL0, gpu::WinGPUOptions opt = gpu::WinGPUOptions())
-        : Pane_Farm<tuple_t, result_t>(typename Pane_Farm<tuple_t, result_t>::engines_tag{}, nullptr, nullptr, win_len, slide_len,
-                                       triggering_delay, type, plq_parallelism, wlq_parallelism, std::move(name), ordered, opt_level) {
-        constexpr bool gpu_plq = meta::is_gpu_stage_func<plq_t>();
-        constexpr bool gpu_wlq = meta::is_gpu_stage_func<wlq_t>();
-        static_assert(gpu_plq != gpu_wlq, "WindFlow Compilation Error - Pane_Farm_GPU: exactly one of PLQ and WLQ must be a device functor");
-        win_engine_maker_t m1, m2;
-        if constexpr (gpu_plq) {
-            m1 = gpu_win_engine<tuple_t, result_t>(plq, cfg, opt, closing, this->hub_);
-            m2 = cpu_win_engine<result_t, result_t>(wlq, closing, this->hub_);
-        } else {
-            m1 = cpu_win_engine<tuple_t, result_t>(plq, closing, this->hub_);
-            m2 = gpu_win_engine<result_t, result_t>(wlq, cfg, opt, closing, this->hub_);
-        }
-        this->set_engines(std::move(m1), std::move(m2));
-    }
-    bool isGPUOperator() const override { return true; }
-};
-
-template <typename tuple_t, typename result_t>
-class Win_MapReduce_GPU : public Win_MapReduce<tuple_t, result_t> {
-public:
-    template <typename map_t, typename reduce_t>
-    Win_MapReduce_GPU(map_t map, reduce_t reduce, uint64_t win_len, uint64_t slide_len, uint64_t triggering_delay, win_type_t type,
-                      size_t map_parallelism, size_t reduce_parallelism, std::string name, GPUConfig cfg, meta::closing_func_t closing = nullptr,
-                      bool ordered = true, opt_level_t opt_level = LEVEL0, gpu::WinGPUOptions opt = gpu::WinGPUOptions())
-        : Win_MapReduce<tuple_t, result_t>(typename Win_MapReduce<tuple_t, result_t>::engines_tag{}, nullptr, nullptr, win_len, slide_len,
-                                           triggering_delay, type, map_parallelism, reduce_parallelism, std::move(name), ordered, opt_level) {
-        constexpr bool gpu_map = meta::is_gpu_stage_func<map_t>();
-        constexpr bool gpu_red = meta::is_gpu_stage_func<reduce_t>();
-        static_assert(gpu_map != gpu_red, "WindFlow Compilation Error - Win_MapReduce_GPU: exactly one of MAP and REDUCE must be a device functor");
-        win_engine_maker_t m1, m2;
-        if constexpr (gpu_map) {
-            m1 = gpu_win_engine<tuple_t, result_t>(map, cfg, opt, closing, this->hub_);
-            m2 = cpu_win_engine<result_t, result_t>(reduce, closing, this->hub_);
-        } else {
-            m1 = cpu_win_engine<tuple_t, result_t>(map, closing, this->hub_);
-            m2 = gpu_win_engine<result_t, result_t>(reduce, cfg, opt, closing, this->hub_);
-        }
-        this->set_engines(std::move(m1), std::move(m2));
-    }
-    bool isGPUOperator() const override { return true; }
 };
 
 }  // namespace wf
