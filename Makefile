@@ -5,7 +5,8 @@ CXX      ?= g++
 ARCH     ?= gfx950
 INC      := -Iwindflow_amd/include -Iwindflow_amd/csrc -Itests/cpp
 CXXFLAGS := -O2 -std=c++17 -Wall -Wextra $(INC)
-HIPFLAGS := --offload-arch=$(ARCH) -O2 -std=c++17 $(INC)
+# -unroll-runtime: see windflow_amd/build.py DEVICE_FLAGS
+HIPFLAGS := --offload-arch=$(ARCH) -O2 -std=c++17 -mllvm -unroll-runtime $(INC)
 
 CPU_BINS := tests/cpp/bin/smoke_basic_ops tests/cpp/bin/test_mp_windows tests/cpp/bin/test_graphs tests/cpp/bin/test_runtime \
             tests/cpp/bin/test_api_variants apps/bin/ysb_kf apps/bin/ysb_wmr apps/bin/bench_cpu apps/bin/example_wordcount

@@ -14,6 +14,10 @@ INCLUDE = os.path.join(ROOT, "include")
 CSRC = os.path.join(ROOT, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+# Device code generation: loops whose trip count is only known at run time (the window loop of a user's functor, the per-run
+# loops of the keyed kernels) are unrolled with a remainder loop, so that their loads are issued ahead of their uses instead of
+# one load + full wait per iteration (measured on the opaque window sum: global_load x8 in flight instead of 1).
+DEVICE_FLAGS = ["-mllvm", "-unroll-runtime"]
 
 
 # RCCL: compiled against the headers of the ROCm tree and linked with an RPATH to the same tree, so a native program always
@@ -54,7 +58,7 @@ def build_extension(force=False, verbose=True):
         return out
     cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC,
            "-I" + os.path.join(os.path.dirname(ROOT), "apps", "ysb")]
-    cmd += _pybind_includes() + srcs + ["-o", out, "-lpthread"]
+    cmd += DEVICE_FLAGS + _pybind_includes() + srcs + ["-o", out, "-lpthread"]
     rccl_inc = "/opt/rocm/include/rccl"
     if os.path.isdir(rccl_inc):
         cmd += list(RCCL_FLAGS)
@@ -70,7 +74,7 @@ def build_cpp(src, out, hip=False, extra=()):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if hip:
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC, src, "-o", out, "-lpthread"]
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", *DEVICE_FLAGS, "-I" + INCLUDE, "-I" + CSRC, src, "-o", out, "-lpthread"]
     else:
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I" + INCLUDE, src, "-o", out, "-pthread"]
     cmd += list(extra)

@@ -44,6 +44,24 @@ namespace gpu {
     std::abort();
 }
 
+// LDS a workgroup may allocate on `device`: asked of the device, never assumed (gfx950: 160 KB per CU; earlier CDNA: 64 KB).
+// WF_LDS_LIMIT (bytes) lowers it, e.g. to reproduce the 64 KB tilings of round 2.
+inline size_t max_lds_per_block(int device) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0) v = 64 * 1024;
+    size_t lim = (size_t)v;
+    if (const char* e = std::getenv("WF_LDS_LIMIT")) {
+        const size_t x = (size_t)std::strtoull(e, nullptr, 10);
+        if (x >= 16 * 1024 && x < lim) lim = x;
+    }
+    return lim;
+}
+// kernels that ask for more dynamic LDS than the 64 KB of older parts say so once (a no-op where the runtime does not need it)
+template <typename K>
+inline void allow_dynamic_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 inline int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -255,11 +255,14 @@ __device__ __forceinline__ X wave_shfl_up(const X& v, int d) {
 // loads in one thread).
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_update_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
+    ffat_update_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, FFATKeyState<R>* states, R* trees,
                        R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
                        uint32_t* n_long, L lift, C comb, uint32_t huge_mode = 0, uint32_t huge_len = 0, uint32_t* huge_heads = nullptr,
                        uint32_t* n_huge = nullptr, volatile uint32_t* huge_seen = nullptr, uint32_t batch_no = 0) {
     const uint32_t n = hdr->count;
+    // a batch without a second tuple of any key was not sorted: every tuple is a run of its own, in any order
+    const uint32_t* sslot = sel.keys();
+    const uint32_t* sidx = sel.vals();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
         if (i > 0 && sslot[i - 1] == slot) continue;  // not the head of a run
@@ -940,12 +943,16 @@ public:
             // batches enqueued before the device's first report has reached the host fold their runs with one wave each)
             *huge_seen_ = max_keys * (size_t)FFAT_HUGE_RUN <= batch_cap_ ? 1u : 0u;
         }
-        // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit
-        // (60 KB of dynamic LDS per block of 4 waves)
-        long_layout_ = FFATLongLayout<R>::choose(g_, (60 * 1024) / (BLOCK_THREADS / WAVE));
+        // the long-run kernel stages the tree and the ring of open quanta of a key in LDS when they fit the LDS the device
+        // offers a block of 4 waves (160 KB on gfx950, less 4 KB of slack; hip_utils.hpp max_lds_per_block)
+        const size_t lds_budget = max_lds_per_block(device_) - 4096;
+        long_layout_ = FFATLongLayout<R>::choose(g_, lds_budget / (BLOCK_THREADS / WAVE));
         long_lds_bytes_ = (BLOCK_THREADS / WAVE) * long_layout_.wave_bytes();
-        if (long_lds_bytes_ > 64 * 1024) failwith("Key_FFAT_GPU: result type too large for the LDS staging buffers");
+        if (long_lds_bytes_ > lds_budget) failwith("Key_FFAT_GPU: result type too large for the LDS staging buffers");
+        allow_dynamic_lds(&ffat_update_long_kernel<true, T, R, L, C>, long_lds_bytes_);
+        allow_dynamic_lds(&ffat_update_long_kernel<false, T, R, L, C>, long_lds_bytes_);
         // the engine's kernels run on another stream: wait for the initialisation here
+        dups_.reserve(table_cap_, init.get());
         init.sync();
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), out_capacity, pool_slabs));
@@ -1001,6 +1008,7 @@ public:
     }
     uint64_t graph_launches() const { return graph_launches_; }
     uint64_t presorted_batches() const { return presorted_batches_; }
+    uint64_t probed_batches() const { return dups_.probed_batches(); }
 
 private:
     void enqueue(Batch* in, Batch* out, size_t upper, hipStream_t s) {
@@ -1008,17 +1016,21 @@ private:
         if (upper > 0) {
             const unsigned grid = grid_for(upper);
             // also clears the header of the output batch
-            hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
-                               out->header(), (uint32_t*)nullptr);
             // time-based windows fed by merged, unsynchronised lanes: runs out of timestamp order are folded sequentially by the
             // kernels below; once they report such runs the batches are ordered by (slot, timestamp) first, so that the parallel
             // in-order paths (bulk, huge runs) apply
             batch_no_++;
             const bool presort = g_.is_tb && !use_graphs_ && disorder_.decide(batch_no_);
+            // a batch that holds no key twice skips the sort (decided on the device: primitives.hpp DupProbe)
+            const DupProbe probe = (presort || use_graphs_) ? DupProbe{} : dups_.probe(batch_no_);
+            const SortGate gate = DupMonitor::gate(probe);
+            hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
+                               out->header(), (uint32_t*)nullptr, probe);
             const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1,
                                                          disorder_.ts_bits(), g_.pane_len, disorder_.clamped(), batch_no_, s)
-                                        : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+                                        : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s, gate);
+            const SortedSel sel{sorted.keys, sorted.vals, slot_.data(), idx_.data(), gate};
             if (presort) presorted_batches_++;
             // huge runs: the four extra launches are only made while the stream shows such runs (the short-run kernel reports
             // them through a pinned word; a run that shows up while they are off is handled by the wave-per-run kernel)
@@ -1028,7 +1040,7 @@ private:
                 huge_mode = (seen != 0 && batch_no_ - seen <= HUGE_LINGER_BATCHES) ? 2u : 1u;
             }
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
+                               sel, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), lift_,
                                comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_);
             if (huge_mode == 2) {
@@ -1154,6 +1166,7 @@ private:
     RadixSorter sorter_;
     TsPresorter presorter_;
     DisorderMonitor disorder_;
+    DupMonitor dups_;
     uint64_t presorted_batches_ = 0;
     std::unique_ptr<BatchPool> out_pool_;
 };

@@ -332,6 +332,7 @@ class KeyedContext {
 public:
     KeyedContext(size_t max_keys, size_t state_size, size_t batch_capacity, int device) : state_size_(state_size ? state_size : 1) {
         WF_HIP_CHECK(hipSetDevice(device));
+        lds_budget_ = max_lds_per_block(device) - 4096;  // 160 KB per workgroup on gfx950, less some slack
         // never the legacy (null) stream: its implicit dependencies would break stream captures running in other threads
         Stream init;
         table_cap_ = 2;
@@ -368,12 +369,13 @@ public:
     // per wave {bytes, staged state bytes (0 = the state stays in global memory)}
     std::pair<size_t, uint32_t> long_layout(size_t tuple_bytes, size_t extra_per_tuple) const {
         size_t base = ((WAVE * tuple_bytes + 15) & ~size_t(15)) + ((WAVE * extra_per_tuple + 15) & ~size_t(15));
-        const size_t budget = (60 * 1024) / (BLOCK_THREADS / WAVE);
+        const size_t budget = lds_budget_ / (BLOCK_THREADS / WAVE);
         uint32_t st = 0;
         if (state_size_ % 4 == 0 && base + state_size_ + 16 <= budget) st = (uint32_t)state_size_;
         return {base + ((st + 15) & ~size_t(15)), st};
     }
     size_t state_size() const { return state_size_; }
+    size_t lds_budget() const { return lds_budget_; }
     uint32_t* table_full_counter() const { return full_.data(); }
     uint32_t read_table_full(hipStream_t s) {
         uint32_t v = 0;
@@ -383,7 +385,7 @@ public:
     }
 
 private:
-    size_t state_size_, table_cap_ = 0;
+    size_t state_size_, table_cap_ = 0, lds_budget_ = 60 * 1024;
     int slot_bits_ = 0;
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<char> states_;
@@ -482,7 +484,8 @@ private:
         } else {
             const auto lay = ctx_->long_layout(sizeof(tuple_t), MODE == 1 ? sizeof(RR) : (MODE == 2 ? 1 : 0));
             const size_t lds = (gpu::BLOCK_THREADS / gpu::WAVE) * lay.first;
-            if (lds > 64 * 1024) gpu::failwith("keyed GPU operator: tuple type too large for the LDS staging buffers");
+            if (lds > ctx_->lds_budget()) gpu::failwith("keyed GPU operator: tuple type too large for the LDS staging buffers");
+            gpu::allow_dynamic_lds(&gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>, lds);
             const unsigned lgrid =
                 (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / gpu::KEYED_LONG_RUN / (gpu::BLOCK_THREADS / gpu::WAVE) + 1));
             hipLaunchKernelGGL((gpu::keyed_apply_long_kernel<MODE, tuple_t, RR, F>), dim3(lgrid), dim3(gpu::BLOCK_THREADS), lds, s, d->header(),

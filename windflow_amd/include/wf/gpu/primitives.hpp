@@ -171,25 +171,118 @@ __device__ __forceinline__ uint32_t key_table_slot(unsigned long long* table, ui
     return 0xffffffffu;
 }
 
+// ---- batches in which no key occurs twice need no sort -------------------------------------------------------------
+// The keyed engines sort (slot, index) pairs so that the tuples of a key become a run in arrival order.  A batch that holds
+// at most one tuple of every key (many keys, round-robin or sparse arrivals: the flagship stream) is already "a run per
+// tuple" in any order.  assign_slots_kernel finds out on the fly: every slot carries the number of the last batch that
+// touched it (`stamp`), a tuple that finds the current batch number there is a second tuple of its key.  A per-block LDS
+// filter catches the repeats inside a block first, so streams with few keys do not pile their atomics on a handful of words.
+// The sort kernels are launched with a SortGate and return at once unless the batch reported a repeat; consumers pick the
+// unsorted arrays in that case (SortedSel).
+struct DupProbe {
+    uint32_t* stamp = nullptr;               // [table slots]; nullptr: no probing (the batch is always sorted)
+    uint32_t* dup_batch = nullptr;           // device word: number of the last batch in which a key occurred twice
+    volatile uint32_t* dup_seen = nullptr;   // pinned copy of it for the host (DupMonitor)
+    uint32_t batch_no = 0;
+};
+struct SortGate {
+    const uint32_t* word = nullptr;  // nullptr: always run
+    uint32_t value = 0;
+    __device__ __forceinline__ bool closed() const { return word != nullptr && *word != value; }
+};
+// where the (slot, index) pairs of the batch are: sorted if the gate let the sort run, as assigned otherwise
+struct SortedSel {
+    const uint32_t* sorted_keys;
+    const uint32_t* sorted_vals;
+    const uint32_t* raw_keys;
+    const uint32_t* raw_vals;
+    SortGate gate;
+    __device__ __forceinline__ bool is_sorted() const { return !gate.closed(); }
+    __device__ __forceinline__ const uint32_t* keys() const { return gate.closed() ? raw_keys : sorted_keys; }
+    __device__ __forceinline__ const uint32_t* vals() const { return gate.closed() ? raw_vals : sorted_vals; }
+};
+constexpr uint32_t DUP_LDS_SLOTS = 1024;
+
 // slot[i] = slot of tuple i's key; idx[i] = i.  KeyFn: uint64_t(const T&)
 // First kernel of a keyed batch: it also clears what the later kernels of the batch accumulate into (the header
 // of the output batch, a counter word) - one launch instead of a memset each.
 template <typename T, typename KeyFn>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     assign_slots_kernel(const BatchHeader* hdr, const T* data, unsigned long long* table, uint32_t mask, uint32_t* slot, uint32_t* idx,
-                        uint32_t* n_failed, KeyFn keyfn, BatchHeader* clear_hdr, uint32_t* clear_word) {
+                        uint32_t* n_failed, KeyFn keyfn, BatchHeader* clear_hdr, uint32_t* clear_word, DupProbe probe = DupProbe{}) {
+    __shared__ uint32_t s_seen[DUP_LDS_SLOTS];
     const uint32_t n = hdr->count;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(BatchHeader) / sizeof(uint64_t)) {
         if (clear_hdr) reinterpret_cast<uint64_t*>(clear_hdr)[threadIdx.x] = 0;
         if (clear_word && threadIdx.x == 0) *clear_word = 0;
     }
+    const bool probing = probe.stamp != nullptr;
+    if (probing) {
+        for (uint32_t k = threadIdx.x; k < DUP_LDS_SLOTS; k += BLOCK_THREADS) s_seen[k] = 0xffffffffu;
+        __syncthreads();
+    }
+    bool dup = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t s = key_table_slot(table, mask, (unsigned long long)keyfn(data[i]));
         if (s == 0xffffffffu) atomicAdd(n_failed, 1u);
         slot[i] = s;
         idx[i] = i;
+        if (probing && s != 0xffffffffu) {
+            // (the same slot twice under one LDS word = a repeat inside this block; a different slot just evicts)
+            if (atomicExch(&s_seen[(s * 2654435761u) >> 22], s) == s)
+                dup = true;
+            else if (atomicMax(&probe.stamp[s], probe.batch_no) == probe.batch_no)
+                dup = true;
+        }
+    }
+    if (probing && __ballot(dup) != 0 && lane_id() == 0) {
+        if (atomicExch(probe.dup_batch, probe.batch_no) != probe.batch_no && probe.dup_seen != nullptr) *probe.dup_seen = probe.batch_no;
     }
 }
+
+// Host side of the probe: batches are probed unless repeats keep showing - then the probe is switched off (its atomics buy
+// nothing, every batch is sorted) and tried again on one batch after `LINGER` batches.
+class DupMonitor {
+public:
+    DupMonitor() {
+        WF_HIP_CHECK(hipHostMalloc((void**)&seen_, 64, hipHostMallocDefault));
+        *seen_ = 0;
+        if (const char* e = std::getenv("WF_SORT_SKIP")) enabled_ = std::atoi(e) != 0;
+    }
+    ~DupMonitor() {
+        if (seen_) (void)hipHostFree((void*)seen_);
+    }
+    DupMonitor(const DupMonitor&) = delete;
+    DupMonitor& operator=(const DupMonitor&) = delete;
+    void reserve(size_t table_slots, hipStream_t s) {
+        stamp_.resize(table_slots);
+        word_.resize(1);
+        WF_HIP_CHECK(hipMemsetAsync(stamp_.data(), 0, stamp_.bytes(), s));
+        WF_HIP_CHECK(hipMemsetAsync(word_.data(), 0, sizeof(uint32_t), s));
+    }
+    // called once per batch before its kernels are enqueued; batch numbers start at 1
+    DupProbe probe(uint32_t batch_no) {
+        if (!enabled_ || stamp_.size() == 0) return DupProbe{};
+        const uint32_t seen = *seen_;
+        if (seen != last_seen_) {
+            last_seen_ = seen;
+            off_until_ = batch_no + LINGER;
+        }
+        if (batch_no < off_until_) return DupProbe{};
+        probed_++;
+        return DupProbe{stamp_.data(), word_.data(), seen_, batch_no};
+    }
+    static SortGate gate(const DupProbe& p) { return p.stamp ? SortGate{p.dup_batch, p.batch_no} : SortGate{}; }
+    uint64_t probed_batches() const { return probed_; }
+
+private:
+    static constexpr uint32_t LINGER = 64;
+    volatile uint32_t* seen_ = nullptr;
+    bool enabled_ = true;
+    uint32_t last_seen_ = 0, off_until_ = 0;
+    uint64_t probed_ = 0;
+    DeviceBuffer<uint32_t> stamp_, word_;
+};
 
 // ---------------------------------------------------------------------------
 // stable LSD radix sort of (key32, value32) pairs, 8 bits per pass
@@ -199,8 +292,9 @@ constexpr int RS_TILE = BLOCK_THREADS * RS_ITEMS;  // 2048 pairs per block
 constexpr int RS_BINS = 256;
 
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    radix_hist_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/) {
+    radix_hist_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/, SortGate gate) {
     __shared__ uint32_t s_hist[RS_BINS];
+    if (gate.closed()) return;
     const uint32_t n = *n_ptr;
     const uint32_t tile = blockIdx.x;
     s_hist[threadIdx.x] = 0;
@@ -222,11 +316,12 @@ template <bool RAW>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     radix_scatter_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
                          uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
-                         const uint32_t* bin_totals /*[bin]*/) {
+                         const uint32_t* bin_totals /*[bin]*/, SortGate gate) {
     constexpr int NW = BLOCK_THREADS / WAVE;
     __shared__ uint32_t s_cnt[RS_ITEMS * NW][RS_BINS];  // per (item round, wave) digit counts -> 32 KiB
     __shared__ uint32_t s_bin_base[RS_BINS];
     __shared__ uint32_t s_wsum[NW];
+    if (gate.closed()) return;
     uint32_t tile_off = 0;  // tuples of this thread's digit in the tiles before this one
     {
         // exclusive scan of the 256 bin totals (one value per thread)
@@ -299,9 +394,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 // per-bin exclusive scan of the digit-major histogram: block b scans hist[b][0..n_tiles)
 // and publishes the bin total; the scatter kernel adds the prefix over bins itself.
 // (256 independent blocks instead of one serial block over 256*n_tiles entries.)
-__global__ void __launch_bounds__(BLOCK_THREADS) radix_bin_scan_kernel(uint32_t* hist, uint32_t n_tiles, uint32_t* bin_totals) {
+__global__ void __launch_bounds__(BLOCK_THREADS) radix_bin_scan_kernel(uint32_t* hist, uint32_t n_tiles, uint32_t* bin_totals, SortGate gate) {
     __shared__ uint32_t s_wave[BLOCK_THREADS / WAVE];
     __shared__ uint32_t s_carry;
+    if (gate.closed()) return;
     uint32_t* row = hist + (size_t)blockIdx.x * n_tiles;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -333,8 +429,9 @@ constexpr int RSW_BITS = 11;
 constexpr int RSW_BINS = 1 << RSW_BITS;
 
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    radix_hist_wide_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/) {
+    radix_hist_wide_kernel(const uint32_t* keys, const uint32_t* n_ptr, uint32_t n_tiles, int shift, uint32_t* hist /*[bin][tile]*/, SortGate gate) {
     __shared__ uint32_t s_hist[RSW_BINS];
+    if (gate.closed()) return;
     const uint32_t n = *n_ptr;
     const uint32_t tile = blockIdx.x;
     for (int b = threadIdx.x; b < RSW_BINS; b += BLOCK_THREADS) s_hist[b] = 0;
@@ -353,13 +450,14 @@ template <bool RAW>  // see radix_scatter_kernel
 __global__ void __launch_bounds__(BLOCK_THREADS)
     radix_scatter_wide_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr,
                               uint32_t n_tiles, int shift, const uint32_t* hist_scanned /*[bin][tile], exclusive within the bin*/,
-                              const uint32_t* bin_totals /*[bin]*/) {
+                              const uint32_t* bin_totals /*[bin]*/, SortGate gate) {
     constexpr int NW = BLOCK_THREADS / WAVE;
     constexpr int PER_THREAD = RSW_BINS / BLOCK_THREADS;  // bins whose global base a thread computes
     __shared__ uint32_t s_cnt[NW][RSW_BINS];               // per-wave running digit counters, then offsets (32 KiB)
     __shared__ uint32_t s_bin_base[RSW_BINS];
     __shared__ uint32_t s_tile_off[RAW ? RSW_BINS : 1];    // RAW: tuples of a digit in the tiles before this one
     __shared__ uint32_t s_wsum[NW];
+    if (gate.closed()) return;
     const int lane = lane_id(), wave = wave_id();
     {
         // exclusive scan of the 2048 bin totals: 8 consecutive bins per thread
@@ -488,7 +586,7 @@ public:
     // sorts the pairs (ping-pong between the caller's arrays and internal buffers) and
     // returns where the sorted pairs live; n_upper bounds the grid, the exact count is
     // read from device memory
-    Sorted sort(uint32_t* keys, uint32_t* vals, const uint32_t* n_dev, size_t n_upper, int bits, hipStream_t s) {
+    Sorted sort(uint32_t* keys, uint32_t* vals, const uint32_t* n_dev, size_t n_upper, int bits, hipStream_t s, SortGate gate = SortGate{}) {
         reserve(n_upper);
         const uint32_t tiles = (uint32_t)((n_upper + RS_TILE - 1) / RS_TILE);
         uint32_t* kin = keys;
@@ -502,24 +600,24 @@ public:
         for (int p = 0; p < n_pass; p++) {
             const int shift = d * p;
             if (d == 8) {
-                hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
+                hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data(), gate);
                 if (fused) {
                     hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles,
-                                       shift, hist_.data(), bin_totals_.data());
+                                       shift, hist_.data(), bin_totals_.data(), gate);
                 } else {
-                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RS_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data(), gate);
                     hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev, tiles,
-                                       shift, hist_.data(), bin_totals_.data());
+                                       shift, hist_.data(), bin_totals_.data(), gate);
                 }
             } else {
-                hipLaunchKernelGGL(radix_hist_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data());
+                hipLaunchKernelGGL(radix_hist_wide_kernel, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, n_dev, tiles, shift, hist_.data(), gate);
                 if (fused) {
                     hipLaunchKernelGGL(radix_scatter_wide_kernel<true>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev,
-                                       tiles, shift, hist_.data(), bin_totals_.data());
+                                       tiles, shift, hist_.data(), bin_totals_.data(), gate);
                 } else {
-                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RSW_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data());
+                    hipLaunchKernelGGL(radix_bin_scan_kernel, dim3(RSW_BINS), dim3(BLOCK_THREADS), 0, s, hist_.data(), tiles, bin_totals_.data(), gate);
                     hipLaunchKernelGGL(radix_scatter_wide_kernel<false>, dim3(tiles), dim3(BLOCK_THREADS), 0, s, kin, vin, kout, vout, n_dev,
-                                       tiles, shift, hist_.data(), bin_totals_.data());
+                                       tiles, shift, hist_.data(), bin_totals_.data(), gate);
                 }
             }
             std::swap(kin, kout);

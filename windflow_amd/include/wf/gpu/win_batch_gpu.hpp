@@ -35,6 +35,7 @@
 #pragma once
 #include <algorithm>
 #include <memory>
+#include <numeric>
 #include <type_traits>
 #include <vector>
 
@@ -201,10 +202,13 @@ constexpr uint32_t WB_NO_RUN = 0xffffffffu;  // WinKeyState::cur_run of a key wh
 
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_runs_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const unsigned long long* table,
+    wb_runs_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, const unsigned long long* table,
                    WinKeyState* states, WinRun* runs, uint32_t* work_len, T* carry, WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t quiet_ok,
                    uint32_t* unsorted_stamp, uint32_t batch_no, volatile uint32_t* disorder_seen) {
     const uint32_t n = hdr->count;
+    // (a batch that holds no key twice was not sorted: every tuple is a run of its own, primitives.hpp DupProbe)
+    const uint32_t* sslot = sel.keys();
+    const uint32_t* sidx = sel.vals();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = sslot[i];
         if (i > 0 && sslot[i - 1] == slot) {  // not the head of a run
@@ -319,10 +323,12 @@ __device__ __forceinline__ uint32_t wb_count_below(At at, uint32_t n, uint64_t x
 
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_gather_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const WinKeyState* states, WinRun* runs,
+    wb_gather_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, const WinKeyState* states, WinRun* runs,
                      const uint32_t* work_off, const T* carry, T* work, const WinCtl* ctl, WinCounters* ctr, WinGeometry g,
                      const uint32_t* unsorted_stamp, uint32_t batch_no) {
     const uint32_t n = hdr->count;
+    const uint32_t* sslot = sel.keys();
+    const uint32_t* sidx = sel.vals();
     const uint32_t n_runs = ctl->n_runs;
     // A run that is in ordinal order (the common case; always after the (slot, timestamp) pre-sort) is MERGED with the carried
     // tuples of its key, which are in order too: the position of every tuple in the segment is its own index plus the number
@@ -550,28 +556,42 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 // LDS-tiled form of the same evaluation, used whenever a window fits the tile: consecutive windows of a key overlap by
 // win - slide tuples, so a workgroup takes `group` consecutive windows, stages the span they cover -
-// (group - 1) * slide + win tuples - in LDS ONCE with all its 256 threads (coalesced 8-byte loads), and `group` threads then
-// run the user's function on the staged copy: the sequential loop of an opaque functor pays LDS latency per tuple instead
-// of a trip to L2 / HBM, and every tuple is fetched once per group instead of once per window it belongs to.  (The
-// reference's K1 reads every window from global memory, win_seq_gpu.hpp:56-80.)  A group whose span does not fit (windows
-// of different keys far apart, the end-of-stream flush over scattered carry areas) falls back to global pointers.
-constexpr uint32_t WB_TILE_BYTES = 64 * 1024;
+// (group - 1) * slide + win tuples - in LDS ONCE with all its threads (coalesced 8-byte loads), and `group` threads then
+// run the user's function on the staged copy: every tuple is fetched once per group instead of once per window it belongs
+// to, and the sequential loop of an opaque functor reads LDS.  (The reference's K1 reads every window from global memory,
+// win_seq_gpu.hpp:56-80.)  A group whose span does not fit (windows of different keys far apart, the end-of-stream flush
+// over scattered carry areas) falls back to global pointers.
+//  * The tile is sized from the LDS the device offers (hip_utils.hpp max_lds_per_block: 160 KB on gfx950 - win 1024 / slide
+//    128 of 40-byte tuples: 25 windows per workgroup, 5 with the 64 KB of older parts) and a workgroup is 16 waves.
+//  * The function is called from two branches - staged window / window in global memory - so that the compiler knows the
+//    address space of `data` in each: ds_read / global_load instructions, unrolled and issued ahead of their uses, instead
+//    of one flat_load + full wait per tuple (measured: the dependent-load loop of an opaque sum was 127 cycles per tuple).
+//  * Which thread takes which window: the windows of a group are `slide` tuples apart, so lanes of one wave that read the
+//    same position of consecutive windows hit LDS banks slide * sizeof(T) / 4 words apart - the same bank for every lane
+//    when that is a multiple of 64 (slide 128 x 40 B).  The contract (const T* data, contiguous) rules out a skewed layout,
+//    so the host picks the thread -> window map with fewer lanes per busy bank: consecutive windows on consecutive lanes
+//    (`by_wave` = 0), or dealt round-robin to the 16 waves (1: window k on wave k % 16, lane k / 16).
+constexpr int WB_TILE_THREADS = 1024;
+constexpr int WB_TILE_WAVES = WB_TILE_THREADS / WAVE;
+constexpr unsigned WB_TILE_GRID = 1024;
+constexpr size_t WB_TILE_STATIC_LDS = 256;  // the kernel's own words, kept out of the dynamic budget
 template <typename T, typename R, typename F>
-__global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_eval_tile_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, uint32_t group, char* scratch,
-                        size_t scratch_size, F f) {
+__global__ void __launch_bounds__(WB_TILE_THREADS)
+    wb_eval_tile_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, uint32_t group, uint32_t tile_tuples,
+                        uint32_t by_wave, char* scratch, size_t scratch_size, F f) {
     extern __shared__ __align__(16) char wb_tile_smem[];
     __shared__ unsigned long long s_lo, s_hi;
     // staged in the widest words the tuple type is aligned to
     typedef std::conditional_t<alignof(T) % 8 == 0, uint64_t, std::conditional_t<alignof(T) % 4 == 0, uint32_t, uint8_t>> raw_word_t;
     typedef raw_word_t __attribute__((may_alias)) word_t;
-    constexpr uint32_t TILE_TUPLES = WB_TILE_BYTES / sizeof(T);
     T* tile = reinterpret_cast<T*>(wb_tile_smem);
     uint32_t n_win = ctl->win_total;
     if (n_win > out_cap) n_win = out_cap;
     const uint32_t n_groups = (n_win + group - 1) / group;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     char* my_scratch = scratch_size ? scratch + (size_t)tid * scratch_size : nullptr;
+    // the window of a group this thread evaluates
+    const uint32_t k = by_wave ? (uint32_t)lane_id() * WB_TILE_WAVES + (uint32_t)wave_id() : threadIdx.x;
     for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
         const uint32_t w0 = gi * group;
         const uint32_t cnt = n_win - w0 < group ? n_win - w0 : group;
@@ -581,23 +601,28 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         }
         __syncthreads();
         WinDesc d{};
-        const bool mine = threadIdx.x < cnt;
+        const bool mine = k < cnt;
         if (mine) {
-            d = desc[w0 + threadIdx.x];
+            d = desc[w0 + k];
             atomicMin(&s_lo, (unsigned long long)d.off);
             atomicMax(&s_hi, (unsigned long long)(d.off + d.len));
         }
         __syncthreads();
         const uint64_t lo = s_lo, hi = s_hi;
-        const bool fits = hi >= lo && hi - lo <= (uint64_t)TILE_TUPLES;
+        const bool fits = hi >= lo && hi - lo <= (uint64_t)tile_tuples;
         if (fits) {
             const word_t* src = reinterpret_cast<const word_t*>(base + lo);
             word_t* dst = reinterpret_cast<word_t*>(tile);
             const uint32_t words = (uint32_t)(hi - lo) * (uint32_t)(sizeof(T) / sizeof(raw_word_t));
-            for (uint32_t k = threadIdx.x; k < words; k += BLOCK_THREADS) dst[k] = src[k];
+            for (uint32_t x = threadIdx.x; x < words; x += WB_TILE_THREADS) dst[x] = src[x];
         }
         __syncthreads();
-        if (mine) f(d.gwid, fits ? static_cast<const T*>(tile + (d.off - lo)) : base + d.off, (size_t)d.len, &out[w0 + threadIdx.x], my_scratch, scratch_size);
+        if (mine) {
+            if (fits)
+                f(d.gwid, static_cast<const T*>(tile + (d.off - lo)), (size_t)d.len, &out[w0 + k], my_scratch, scratch_size);
+            else
+                f(d.gwid, base + d.off, (size_t)d.len, &out[w0 + k], my_scratch, scratch_size);
+        }
         __syncthreads();
     }
 }
@@ -915,7 +940,7 @@ public:
         WF_HIP_CHECK(hipMemsetAsync(ctl_.data(), 0, sizeof(WinCtl), init.get()));
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(WinCounters), init.get()));
-        if (scratch_size_ > 0) scratch_.resize((size_t)EVAL_GRID * BLOCK_THREADS * scratch_size_);
+        if (scratch_size_ > 0) scratch_.resize(std::max((size_t)EVAL_GRID * BLOCK_THREADS, (size_t)WB_TILE_GRID * WB_TILE_THREADS) * scratch_size_);
         if constexpr (is_map_reduce_t<F>::value) {
             if (func_.stripes > BLOCK_THREADS) failwith("Win_MapReduce_GPU: at most 256 map stripes per window");
             // scratch of a workgroup: a whole window (count-based), or what a key can hold between two batches plus a batch (time-based)
@@ -927,22 +952,40 @@ public:
             mr_area_.resize((size_t)mr_grid_ * longest);
             mr_partials_.resize((size_t)mr_grid_ * func_.stripes);
         }
-        // windows per workgroup of the LDS-tiled evaluation: as many consecutive windows as share one 64 KB tile (0: a window
-        // alone does not fit, evaluate from global memory).  Time-based windows are sized as if a key ticked once per time unit,
-        // bounded by what a key can carry; a group that turns out larger than the tile falls back to global memory by itself.
+        // windows per workgroup of the LDS-tiled evaluation: as many consecutive windows as share one tile of the LDS the device
+        // offers (0: a window alone does not fit, evaluate from global memory).  Time-based windows are sized as if a key ticked
+        // once per time unit, bounded by what a key can carry; a group that turns out larger than the tile falls back to global
+        // memory by itself.
         {
-            const uint64_t tile_tuples = WB_TILE_BYTES / sizeof(T);
+            const size_t lds = max_lds_per_block(device_);
+            const uint64_t tile_max = lds > WB_TILE_STATIC_LDS ? (lds - WB_TILE_STATIC_LDS) / sizeof(T) : 0;
             uint64_t w = g_.win, sl = g_.slide;
             if (g_.is_tb && w > g_.carry_cap) {
                 sl = std::max<uint64_t>(1, sl * g_.carry_cap / w);
                 w = g_.carry_cap;
             }
-            if (w <= tile_tuples) tile_group_ = (uint32_t)std::min<uint64_t>(BLOCK_THREADS, (tile_tuples - w) / sl + 1);
+            if (w <= tile_max) {
+                tile_group_ = (uint32_t)std::min<uint64_t>(WB_TILE_THREADS, (tile_max - w) / sl + 1);
+                // count-based windows: exactly the span of the group; time-based ones: everything there is (the estimate is loose)
+                tile_tuples_ = (uint32_t)(g_.is_tb ? tile_max : std::min<uint64_t>(tile_max, (uint64_t)(tile_group_ - 1) * sl + w));
+                // lanes per busy LDS bank under the two thread -> window maps (see the kernel)
+                auto lanes_per_bank = [&](uint64_t lane_stride_windows, uint32_t active) {
+                    const uint64_t words = (sl * lane_stride_windows * sizeof(T) / 4) % 64;
+                    const uint32_t banks = words == 0 ? 1u : (uint32_t)(64 / std::gcd<uint64_t>(words, 64));
+                    return (double)active / (double)std::min(active, banks);
+                };
+                const uint32_t act_a = std::min<uint32_t>(WAVE, tile_group_), act_b = (tile_group_ + WB_TILE_WAVES - 1) / WB_TILE_WAVES;
+                tile_by_wave_ = lanes_per_bank(WB_TILE_WAVES, act_b) < lanes_per_bank(1, act_a) ? 1u : 0u;
+            }
             if (const char* e = std::getenv("WF_WIN_TILE")) {
                 if (std::atoi(e) == 0) tile_group_ = 0;
             }
             if (const char* e = std::getenv("WF_WIN_QUIET_RUNS")) quiet_runs_ = std::atoi(e) != 0;
+            if constexpr (!is_map_reduce_t<F>::value && !is_wave_reduce_t<F>::value) {
+                if (tile_group_ > 0) allow_dynamic_lds(&wb_eval_tile_kernel<T, R, F>, (size_t)tile_tuples_ * sizeof(T));
+            }
         }
+        dups_.reserve(table_cap_, init.get());
         init.sync();
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), g_.out_cap, pool_slabs));
@@ -971,24 +1014,28 @@ public:
         const unsigned grid = grid_for(upper);
         const size_t runs_upper = std::min<size_t>(upper, n_tab_);
         const unsigned rgrid = grid_for(runs_upper);
-        // also clears the header of the output batch and the run counter
-        hipLaunchKernelGGL((assign_slots_kernel<T, KeyFn>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.data(),
-                           (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyFn{}, out->header(),
-                           &ctl_.data()->n_runs);
         // ordinals that are not assigned here (timestamps, user ids) may arrive out of order: once the device has reported runs
         // that are, or when the caller knows its input is a merge of unsynchronised lanes, the batch is ordered by (slot,
         // timestamp) instead of (slot, arrival)
         batch_no_++;
         const bool presort = g_.is_tb && !g_.renumber && disorder_.decide(batch_no_);
+        // a batch that holds no key twice skips the sort (decided on the device: primitives.hpp DupProbe)
+        const DupProbe probe = presort ? DupProbe{} : dups_.probe(batch_no_);
+        const SortGate gate = DupMonitor::gate(probe);
+        // also clears the header of the output batch and the run counter
+        hipLaunchKernelGGL((assign_slots_kernel<T, KeyFn>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.data(),
+                           (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyFn{}, out->header(),
+                           &ctl_.data()->n_runs, probe);
         const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1, 32,
                                                      1, disorder_.clamped(), batch_no_, s)
-                                    : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
+                                    : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s, gate);
+        const SortedSel sel{sorted.keys, sorted.vals, slot_.data(), idx_.data(), gate};
         if (presort) presorted_batches_++;
-        hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
+        hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sel,
                            table_.data(), states_.data(), runs_.data(), work_len_.data(), carry_.data(), ctl_.data(), counters_.data(), g_,
                            quiet_runs_ ? 1u : 0u, unsorted_stamp_.data(), batch_no_, disorder_.seen());
         exclusive_scan_u32(work_len_.data(), work_off_.data(), runs_upper, &ctl_.data()->work_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
-        hipLaunchKernelGGL((wb_gather_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys, sorted.vals,
+        hipLaunchKernelGGL((wb_gather_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sel,
                            states_.data(), runs_.data(), work_off_.data(), carry_.data(), work_.data(), ctl_.data(), counters_.data(), g_,
                            unsorted_stamp_.data(), batch_no_);
         if (!g_.renumber)
@@ -1070,8 +1117,9 @@ private:
                                desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, func_.lift, func_.comb);
         } else if (tile_group_ > 0) {
             const unsigned groups = (unsigned)((g_.out_cap + tile_group_ - 1) / tile_group_);
-            hipLaunchKernelGGL((wb_eval_tile_kernel<T, R, F>), dim3(std::min(groups, EVAL_GRID)), dim3(BLOCK_THREADS), WB_TILE_BYTES, s, base,
-                               desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, tile_group_, scratch_.data(), scratch_size_, func_);
+            hipLaunchKernelGGL((wb_eval_tile_kernel<T, R, F>), dim3(std::min(groups, WB_TILE_GRID)), dim3(WB_TILE_THREADS), (size_t)tile_tuples_ * sizeof(T),
+                               s, base, desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, tile_group_, tile_tuples_, tile_by_wave_,
+                               scratch_.data(), scratch_size_, func_);
         } else {
             hipLaunchKernelGGL((wb_eval_kernel<T, R, F>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base, desc_.data(), out->template data<R>(),
                                ctl_.data(), g_.out_cap, scratch_.data(), scratch_size_, func_);
@@ -1084,7 +1132,7 @@ private:
     WinGeometry g_{};
     size_t table_cap_ = 0, batch_cap_ = 0, n_tab_ = 0;
     int slot_bits_ = 0;
-    uint32_t tile_group_ = 0;
+    uint32_t tile_group_ = 0, tile_tuples_ = 0, tile_by_wave_ = 0;
     bool quiet_runs_ = true;  // short runs that fire no window are appended to the carry areas in place (wb_runs_kernel)
     DeviceBuffer<unsigned long long> table_;
     DeviceBuffer<WinKeyState> states_;
@@ -1092,6 +1140,7 @@ private:
     DeviceBuffer<uint32_t> slot_, idx_, work_len_, work_off_, n_fire_, win_off_, unsorted_stamp_;
     TsPresorter presorter_;
     DisorderMonitor disorder_;
+    DupMonitor dups_;
     uint32_t batch_no_ = 0;
     uint64_t presorted_batches_ = 0;
     DeviceBuffer<WinRun> runs_;
