@@ -10,7 +10,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O2 -std=c++17 -mllvm -unroll-runtime $(INC)
 
 CPU_BINS := tests/cpp/bin/smoke_basic_ops tests/cpp/bin/test_mp_windows tests/cpp/bin/test_graphs tests/cpp/bin/test_runtime \
             tests/cpp/bin/test_api_variants apps/bin/ysb_kf apps/bin/ysb_wmr apps/bin/bench_cpu apps/bin/example_wordcount
-GPU_BINS := tests/cpp/bin/test_mp_windows_gpu tests/cpp/bin/test_gpu_keyed apps/bin/ysb_gpu apps/bin/bench_ops_gpu apps/bin/bench_win_gpu \
+GPU_BINS := tests/cpp/bin/test_mp_windows_gpu tests/cpp/bin/test_mp_windows_gpu_fixedkey tests/cpp/bin/test_gpu_keyed apps/bin/ysb_gpu apps/bin/bench_ops_gpu apps/bin/bench_win_gpu \
             apps/bin/example_gpu_pipeline
 HEADERS  := $(shell find windflow_amd/include windflow_amd/csrc tests/cpp apps/ysb -name '*.hpp')
 
@@ -24,6 +24,10 @@ tests/cpp/bin/%: tests/cpp/%.cpp $(HEADERS)
 tests/cpp/bin/%: tests/cpp/%.hip $(HEADERS)
 	@mkdir -p $(@D)
 	$(HIPCC) $(HIPFLAGS) $< -o $@ -lpthread
+# the window suite keyed by 16-byte fixed-size keys (the reference's *_string programs)
+tests/cpp/bin/test_mp_windows_gpu_fixedkey: tests/cpp/test_mp_windows_gpu.hip $(HEADERS)
+	@mkdir -p $(@D)
+	$(HIPCC) $(HIPFLAGS) -DWF_TEST_FIXED_KEY $< -o $@ -lpthread
 apps/bin/%: apps/ysb/%.cpp $(HEADERS)
 	@mkdir -p $(@D)
 	$(CXX) $(CXXFLAGS) -Iapps/ysb $< -o $@ -pthread

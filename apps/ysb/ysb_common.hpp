@@ -74,9 +74,9 @@ struct WinResult {
     }
 };
 
-// campaigns and their ads.  Ad ids are a fixed permutation of [0, n_ads): ad(i) = (A*i + B) mod n_ads, so the
-// CPU versions can join through a hash map (as the reference does) and the GPU version can invert the permutation
-// arithmetically - no lookup table to replicate on every GPU.
+// campaigns and their ads.  Ad ids are a fixed permutation of [0, n_ads): ad(i) = (A*i + B) mod n_ads.  The CPU versions
+// join through the hash map below (as the reference does), the GPU versions through a device hash table + record table built
+// from it (ysb_gpu_common.hpp DeviceCampaignTables).
 class Campaigns {
 public:
     static constexpr uint64_t A = 7919, B = 123;

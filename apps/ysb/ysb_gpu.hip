@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
     std::vector<int> placement;
     for (size_t i = 0; i < std::max<size_t>(1, o.gpus); i++) placement.push_back((int)i);
     ysb::Campaigns campaigns;
+    ysb::DeviceCampaignTables tables(campaigns);  // hash table + record table of the join, one copy per GPU in use
     ysb::Metrics metrics;
     const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
 
@@ -42,7 +43,7 @@ int main(int argc, char** argv) {
     MultiPipe& pipe = graph.add_source(*source);
     auto filter = FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(o.par1).withGPUPlacement(placement).build_unique();
     pipe.add(*filter);
-    auto join = MapGPU_Builder(ysb::JoinGPU(campaigns)).withName("ysb_join_gpu").withParallelism(o.par1).withGPUPlacement(placement).build_unique();
+    auto join = MapGPU_Builder(ysb::JoinGPU(tables)).withName("ysb_join_gpu").withParallelism(o.par1).withGPUPlacement(placement).build_unique();
     pipe.chain(*join);
     std::unique_ptr<Basic_Operator> agg;
     if (engine == "farm") {

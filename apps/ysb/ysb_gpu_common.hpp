@@ -2,11 +2,15 @@
 // straight into pinned slabs, and the batch sink.  Shared by apps/ysb/ysb_gpu.hip (one process, one or more local
 // replicas), apps/ysb/ysb_gpu_dist.hip (one process per GPU, campaigns partitioned across ranks through Exchange_GPU)
 // and the pipeline bench.py drives.  The whole query stays in HBM:
-//   Batch_Source -> Filter_GPU (event_type == view) -> Map_GPU (ad -> campaign) -> [KeyBy / Exchange_GPU]
+//   Batch_Source -> Filter_GPU (event_type == view) -> Map_GPU (hash join ad -> campaign record) -> [KeyBy / Exchange_GPU]
 //                -> Key_FFAT_GPU (10 s tumbling time window per campaign: count + last update) -> Batch_Sink
 // Reference harness: /root/reference/src/yahoo_test_cpu/ysb_nodes.hpp:54-220 (per-tuple CPU operators, Key_Farm or
 // Win_MapReduce aggregation).
 #pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+
 #include <wf/windflow_gpu.hpp>
 
 #include "ysb_common.hpp"
@@ -21,16 +25,88 @@ struct ViewFilterGPU {
 struct AdTypeSplit {
     __host__ __device__ size_t operator()(const Event& e) const { return e.ad_type & 1u; }
 };
-// stream-table join without a table: ad ids are a fixed permutation of [0, n_ads) (ysb::Campaigns), inverted arithmetically
+// ---- stream-table join on the device ------------------------------------------------------------------------------------
+// Reference: YSBJoin (/root/reference/src/yahoo_test_cpu/ysb_nodes.hpp:147-175) probes an unordered_map ad id -> row and reads
+// the campaign_record of that row from a relational table, per view.  The same two steps here, in HBM: an open-addressing
+// hash table (ad id -> row, linear probing, load factor <= 1/2) and the table of records; both are a few tens of KB and stay
+// in the vector caches of the CUs.  One copy per GPU, uploaded by the replica that first runs there (Map_GPU bind_device).
+struct CampaignRecord {
+    uint64_t ad_id, cmp_id;
+};
+class DeviceCampaignTables {
+public:
+    static constexpr unsigned long long EMPTY = ~0ull;
+    struct View {
+        const unsigned long long* ad_keys = nullptr;  // [mask + 1] ad id or EMPTY
+        const uint32_t* rows = nullptr;               // [mask + 1] row of the ad in `records`
+        const CampaignRecord* records = nullptr;
+        uint32_t mask = 0;
+    };
+    explicit DeviceCampaignTables(const Campaigns& c) {
+        size_t cap = 16;
+        while (cap < 2 * c.n_ads()) cap <<= 1;
+        keys_.assign(cap, EMPTY);
+        rows_.assign(cap, 0);
+        for (const auto& kv : c.ad_to_campaign()) {
+            uint32_t h = (uint32_t)wf::gpu::mix64(kv.first) & (uint32_t)(cap - 1);
+            while (keys_[h] != EMPTY) h = (h + 1) & (uint32_t)(cap - 1);
+            keys_[h] = kv.first;
+            rows_[h] = (uint32_t)records_.size();
+            records_.push_back(CampaignRecord{kv.first, kv.second});
+        }
+    }
+    View view(int device) {
+        std::lock_guard<std::mutex> l(m_);
+        auto it = per_device_.find(device);
+        if (it == per_device_.end()) {
+            WF_HIP_CHECK(hipSetDevice(device));
+            auto d = std::make_unique<OnDevice>();
+            d->keys.resize(keys_.size());
+            d->rows.resize(rows_.size());
+            d->records.resize(records_.size());
+            WF_HIP_CHECK(hipMemcpy(d->keys.data(), keys_.data(), keys_.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            WF_HIP_CHECK(hipMemcpy(d->rows.data(), rows_.data(), rows_.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            WF_HIP_CHECK(hipMemcpy(d->records.data(), records_.data(), records_.size() * sizeof(CampaignRecord), hipMemcpyHostToDevice));
+            it = per_device_.emplace(device, std::move(d)).first;
+        }
+        return View{it->second->keys.data(), it->second->rows.data(), it->second->records.data(), (uint32_t)(keys_.size() - 1)};
+    }
+
+private:
+    struct OnDevice {
+        wf::gpu::DeviceBuffer<unsigned long long> keys;
+        wf::gpu::DeviceBuffer<uint32_t> rows;
+        wf::gpu::DeviceBuffer<CampaignRecord> records;
+    };
+    std::vector<unsigned long long> keys_;
+    std::vector<uint32_t> rows_;
+    std::vector<CampaignRecord> records_;
+    std::mutex m_;
+    std::map<int, std::unique_ptr<OnDevice>> per_device_;
+};
+// the join functor: `tables` must outlive the graph (it owns the device copies)
 struct JoinGPU {
-    uint64_t n_ads, per_campaign, inv_a, b;
-    explicit JoinGPU(const Campaigns& c) : n_ads(c.n_ads()), per_campaign(c.ads_per_campaign()), inv_a(c.inverse_multiplier()), b(Campaigns::B) {}
+    DeviceCampaignTables* tables;
+    DeviceCampaignTables::View v;
+    explicit JoinGPU(DeviceCampaignTables& t) : tables(&t) {}
+    void bind_device(int gpu_id) { v = tables->view(gpu_id); }
     __host__ __device__ void operator()(const Event& e, Joined& j) const {
         j.ts = e.ts;
         j.seq = e.seq;
         j.ad_id = e.ad_id;
-        const uint64_t pos = ((e.ad_id % n_ads + n_ads - b % n_ads) % n_ads) * inv_a % n_ads;
-        j.cmp_id = e.ad_id < n_ads ? pos / per_campaign : 0xffffffffull;
+        j.cmp_id = 0xffffffffull;  // unknown ad: belongs to no campaign (the reference drops the event, ysb_nodes.hpp:163-165)
+        uint32_t h = (uint32_t)wf::gpu::mix64(e.ad_id) & v.mask;
+        for (uint32_t probes = 0; probes <= v.mask; probes++) {
+            const unsigned long long k = v.ad_keys[h];
+            if (k == (unsigned long long)e.ad_id) {
+                const CampaignRecord rec = v.records[v.rows[h]];
+                j.ad_id = rec.ad_id;
+                j.cmp_id = rec.cmp_id;
+                return;
+            }
+            if (k == DeviceCampaignTables::EMPTY) return;
+            h = (h + 1) & v.mask;
+        }
     }
 };
 // incremental aggregation of a window: number of views and the latest of them

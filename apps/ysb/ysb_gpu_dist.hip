@@ -33,6 +33,7 @@ struct DistOptions {
 static void run_rank(const DistOptions& d, std::shared_ptr<dist::Transport> tr, int device, ysb::Metrics& metrics, ExchangeStats* xstats) {
     const ysb::Options& o = d.o;
     ysb::Campaigns campaigns;
+    ysb::DeviceCampaignTables tables(campaigns);  // hash table + record table of the join on this rank's GPU
     const auto us = [](uint64_t v) { return std::chrono::microseconds(v); };
     PipeGraph graph("ysb_gpu_dist_rank" + std::to_string(tr->rank()), Mode::DEFAULT);
     auto source = BatchSource_Builder(ysb::BulkEventSource(&campaigns, &metrics, o.seconds, o.events, o.period_us)).withName("ysb_source")
@@ -43,7 +44,7 @@ static void run_rank(const DistOptions& d, std::shared_ptr<dist::Transport> tr, 
     std::vector<std::unique_ptr<Map_GPU<ysb::Event, ysb::Joined>>> joins;
     for (size_t b = 0; b < branches; b++) {
         filters.push_back(FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(o.par1).withGPUConfiguration(device).build_unique());
-        joins.push_back(MapGPU_Builder(ysb::JoinGPU(campaigns)).withName("ysb_join_gpu").withParallelism(o.par1).withGPUConfiguration(device).build_unique());
+        joins.push_back(MapGPU_Builder(ysb::JoinGPU(tables)).withName("ysb_join_gpu").withParallelism(o.par1).withGPUConfiguration(device).build_unique());
     }
     if (d.split_merge) {
         GPUConfig scfg;

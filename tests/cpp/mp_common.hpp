@@ -21,15 +21,26 @@
 
 #include <wf/windflow.hpp>
 
+// Key type of the suite.  -DWF_TEST_FIXED_KEY builds the "string key" twins of the programs (reference:
+// src/mp_test_cpu/mp_common_string.hpp, src/mp_test_gpu/mp_common_string.hpp:44-84 and the four test_mp_gpu_*_cb_string.cpp):
+// keys "key_0", "key_1" ... as 16-byte fixed-size keys, which - unlike std::string - can live in HBM.
+#ifdef WF_TEST_FIXED_KEY
+using test_key_t = wf::FixedKey<16>;
+inline test_key_t make_key(size_t k) { return test_key_t("key_" + std::to_string(k)); }
+#else
+using test_key_t = size_t;
+inline test_key_t make_key(size_t k) { return k; }
+#endif
+
 struct tuple_t {
-    size_t key = 0;
+    test_key_t key{};
     uint64_t id = 0;
     uint64_t ts = 0;
     int64_t value = 0;
     WF_HOST_DEVICE tuple_t() {}
-    WF_HOST_DEVICE tuple_t(size_t k, uint64_t i, uint64_t t, int64_t v) : key(k), id(i), ts(t), value(v) {}
-    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE tuple_t(test_key_t k, uint64_t i, uint64_t t, int64_t v) : key(k), id(i), ts(t), value(v) {}
+    WF_HOST_DEVICE std::tuple<test_key_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(test_key_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;
@@ -37,13 +48,13 @@ struct tuple_t {
 };
 
 struct output_t {
-    size_t key = 0;
+    test_key_t key{};
     uint64_t id = 0;
     uint64_t ts = 0;
     int64_t value = 0;
     WF_HOST_DEVICE output_t() {}
-    WF_HOST_DEVICE std::tuple<size_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
-    WF_HOST_DEVICE void setControlFields(size_t k, uint64_t i, uint64_t t) {
+    WF_HOST_DEVICE std::tuple<test_key_t, uint64_t, uint64_t> getControlFields() const { return {key, id, ts}; }
+    WF_HOST_DEVICE void setControlFields(test_key_t k, uint64_t i, uint64_t t) {
         key = k;
         id = i;
         ts = t;
@@ -67,7 +78,7 @@ class Source_Functor {
 public:
     Source_Functor(size_t len, size_t keys) : len_(len), keys_(keys), ids_(keys, 0) {}
     bool operator()(tuple_t& t) {
-        t.setControlFields(k_, ids_[k_], next_ts_);
+        t.setControlFields(make_key(k_), ids_[k_], next_ts_);
         t.value = (int64_t)ids_[k_]++;
         sent_++;
         k_ = (k_ + 1) % keys_;
@@ -144,17 +155,17 @@ public:
 
 private:
     SinkTotals* totals_;
-    std::map<size_t, uint64_t> last_id_;
+    std::map<test_key_t, uint64_t> last_id_;
 };
 
 // ---- oracle ---------------------------------------------------------------------
 // the stream after Source -> Filter(even) -> FlatMap(x3) -> Map(x2), per key, in
 // timestamp order
-inline std::map<size_t, std::vector<tuple_t>> oracle_stream(size_t len, size_t keys) {
+inline std::map<test_key_t, std::vector<tuple_t>> oracle_stream(size_t len, size_t keys) {
     Source_Functor src(len, keys);
     Filter_Functor fil;
     Map_Functor mp;
-    std::map<size_t, std::vector<tuple_t>> per_key;
+    std::map<test_key_t, std::vector<tuple_t>> per_key;
     bool more = true;
     while (more) {
         tuple_t t;
@@ -179,7 +190,7 @@ struct OracleResult {
 };
 // count-based windows over the arrival (timestamp) order of each key; every opened
 // window is emitted (partial ones at end of stream)
-inline OracleResult oracle_cb(const std::map<size_t, std::vector<tuple_t>>& s, uint64_t win, uint64_t slide) {
+inline OracleResult oracle_cb(const std::map<test_key_t, std::vector<tuple_t>>& s, uint64_t win, uint64_t slide) {
     OracleResult r;
     for (auto& kv : s) {
         const auto& v = kv.second;
@@ -199,7 +210,7 @@ inline OracleResult oracle_cb(const std::map<size_t, std::vector<tuple_t>>& s, u
     return r;
 }
 // time-based windows [w*slide, w*slide+win)
-inline OracleResult oracle_tb(const std::map<size_t, std::vector<tuple_t>>& s, uint64_t win, uint64_t slide) {
+inline OracleResult oracle_tb(const std::map<test_key_t, std::vector<tuple_t>>& s, uint64_t win, uint64_t slide) {
     OracleResult r;
     for (auto& kv : s) {
         const auto& v = kv.second;

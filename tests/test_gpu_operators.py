@@ -13,9 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(HERE, "cpp", "bin")
 
 
-def run_gpu_cpp(args, timeout=110):
-    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_mp_windows_gpu.hip"), os.path.join(BIN, "test_mp_windows_gpu"), hip=True,
-                            extra=["-I" + os.path.join(HERE, "cpp")])
+def run_gpu_cpp(args, timeout=110, fixed_key=False):
+    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_mp_windows_gpu.hip"),
+                            os.path.join(BIN, "test_mp_windows_gpu_fixedkey" if fixed_key else "test_mp_windows_gpu"), hip=True,
+                            extra=["-I" + os.path.join(HERE, "cpp")] + (["-DWF_TEST_FIXED_KEY"] if fixed_key else []))
     r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, WF_QUIET="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
@@ -31,6 +32,17 @@ GPU_OPS = ["seq", "kf", "wf", "pf_plq", "pf_wlq", "wmr_map", "wmr_red", "kff", "
 def test_gpu_window_operators(op, mode):
     win, slide = ("14", "4") if mode == "cb" else ("1000", "300")
     out = run_gpu_cpp(["-t", op, "-m", mode, "-r", 2, "-l", 1200, "-k", 5, "-w", win, "-s", slide])
+    assert out.count("  OK") == 2 and "FAILED" not in out
+
+
+# keys that are not numbers: the reference's four string-keyed GPU programs (src/mp_test_gpu/test_mp_gpu_{kf,wf,pf,wmr}_cb_string.cpp)
+# with 16-byte fixed-size keys "key_<n>" (wf::FixedKey<16>: std::string cannot live in HBM), plus the incremental operator, the
+# all-device two-stage operators and a nesting; time-based for the two engines as well
+@pytest.mark.parametrize("op,mode", [("kf", "cb"), ("wf", "cb"), ("pf_plq", "cb"), ("wmr_map", "cb"), ("kff", "cb"), ("pf_gg", "cb"), ("wmr_gg", "cb"),
+                                     ("kf+pf", "cb"), ("kf", "tb"), ("kff", "tb"), ("kff", "tbd"), ("kf", "tbd")])
+def test_gpu_window_operators_fixed_size_keys(op, mode):
+    win, slide = ("14", "4") if mode == "cb" else ("1000", "300")
+    out = run_gpu_cpp(["-t", op, "-m", mode, "-r", 2, "-l", 1200, "-k", 5, "-w", win, "-s", slide], fixed_key=True)
     assert out.count("  OK") == 2 and "FAILED" not in out
 
 

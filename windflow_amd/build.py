@@ -104,6 +104,9 @@ PROGRAMS = [
     ("tests/cpp/test_api_variants.cpp", "tests/cpp/bin/test_api_variants", False),
     ("tests/cpp/test_mp_windows_gpu.hip", "tests/cpp/bin/test_mp_windows_gpu", True),
     ("tests/cpp/test_gpu_keyed.hip", "tests/cpp/bin/test_gpu_keyed", True),
+    # the same MultiPipe suite keyed by 16-byte fixed-size keys (the reference's *_string programs)
+    ("tests/cpp/test_mp_windows_gpu.hip", "tests/cpp/bin/test_mp_windows_gpu_fixedkey", True, ["-DWF_TEST_FIXED_KEY"]),
+    ("tests/cpp/test_mp_windows.cpp", "tests/cpp/bin/test_mp_windows_fixedkey", False, ["-DWF_TEST_FIXED_KEY"]),
     ("apps/ysb/ysb_kf.cpp", "apps/bin/ysb_kf", False),
     ("apps/ysb/ysb_wmr.cpp", "apps/bin/ysb_wmr", False),
     ("apps/ysb/ysb_gpu.hip", "apps/bin/ysb_gpu", True),

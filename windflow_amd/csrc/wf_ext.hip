@@ -890,7 +890,7 @@ public:
         for (size_t b = 0; b < branches; b++) {
             filter_.push_back(FilterGPU_Builder(ysb::ViewFilterGPU()).withName("ysb_filter_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
                                   .withGPUConfiguration(gpu_id).build_unique());
-            join_.push_back(MapGPU_Builder(ysb::JoinGPU(campaigns_)).withName("ysb_join_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
+            join_.push_back(MapGPU_Builder(ysb::JoinGPU(tables_)).withName("ysb_join_gpu").withParallelism(n_sources).withInFlightBatches(inflight)
                                 .withGPUConfiguration(gpu_id).build_unique());
         }
         if (split_merge) {
@@ -987,6 +987,7 @@ public:
 private:
     size_t n_sources_, n_sinks_, punct_expected_ = 0;
     ysb::Campaigns campaigns_;
+    ysb::DeviceCampaignTables tables_{campaigns_};  // the join's hash table + record table on the device
     std::unique_ptr<wfbench::StepGate[]> gates_;
     PipeGraph graph_;
     std::shared_ptr<YsbTotals> totals_;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <iostream>
 #include <atomic>
@@ -117,6 +118,59 @@ inline size_t hash_of(const T& t) {
     return std::hash<key_of_t<T>>()(key_of(t));
 }
 
+// ---- fixed-size keys ------------------------------------------------------------------------------------------------------
+// Keys of tuples processed by the GPU operators must be trivially copyable: an integer, or a fixed-size value type with
+//     WF_HOST_DEVICE uint64_t hash() const;   WF_HOST_DEVICE bool operator==(const K&) const;
+// of at most 32 bytes (a multiple of 4).  FixedKey<N> is the ready-made one for what applications usually key by when it is
+// not a number - names, UUIDs (the Yahoo benchmark's campaign ids): N bytes, zero-padded, built from a string.  std::hash is
+// specialised to the same hash(), so CPU and GPU operators agree on everything that is derived from a key's hash (routing, the
+// window a replica of a Win_Farm starts at).  (The reference's GPU programs key by std::string,
+// src/mp_test_gpu/mp_common_string.hpp:44-84, and keep the keys on the host; std::string cannot live in HBM.)
+WF_HOST_DEVICE inline uint64_t mix64_key(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+template <size_t N>
+struct FixedKey {
+    static_assert(N % 8 == 0 && N >= 8 && N <= 32, "FixedKey: 8, 16, 24 or 32 bytes");
+    uint64_t w[N / 8];
+    WF_HOST_DEVICE FixedKey() {
+        for (size_t i = 0; i < N / 8; i++) w[i] = 0;
+    }
+    FixedKey(const char* s) : FixedKey(std::string(s)) {}
+    FixedKey(const std::string& s) {
+        char bytes[N] = {0};
+        for (size_t i = 0; i < N && i < s.size(); i++) bytes[i] = s[i];
+        std::memcpy(w, bytes, N);
+    }
+    std::string str() const {
+        char bytes[N + 1];
+        std::memcpy(bytes, w, N);
+        bytes[N] = 0;
+        return std::string(bytes);
+    }
+    WF_HOST_DEVICE bool operator==(const FixedKey& o) const {
+        bool eq = true;
+        for (size_t i = 0; i < N / 8; i++) eq = eq && w[i] == o.w[i];
+        return eq;
+    }
+    WF_HOST_DEVICE bool operator!=(const FixedKey& o) const { return !(*this == o); }
+    WF_HOST_DEVICE bool operator<(const FixedKey& o) const {
+        for (size_t i = 0; i < N / 8; i++)
+            if (w[i] != o.w[i]) return w[i] < o.w[i];
+        return false;
+    }
+    WF_HOST_DEVICE uint64_t hash() const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < N / 8; i++) h = mix64_key(h ^ w[i]);
+        return h;
+    }
+};
+
 // ---- message tagging -------------------------------------------------------
 // Messages between nodes are heap pointers to tuples owned by the receiver.
 // Window operators additionally need "end-of-stream markers": a copy of the last
@@ -134,3 +188,10 @@ inline T* untag(void* p) {
 }
 
 }  // namespace wf
+
+namespace std {
+template <size_t N>
+struct hash<wf::FixedKey<N>> {
+    size_t operator()(const wf::FixedKey<N>& k) const { return (size_t)k.hash(); }
+};
+}  // namespace std

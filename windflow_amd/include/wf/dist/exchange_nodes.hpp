@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const uint64_t ts = (uint64_t)std::get<2>(t.getControlFields());
         unsigned long long k;
         if (ts <= W) {
-            const uint64_t h = mix64((uint64_t)std::get<0>(t.getControlFields()));
+            const uint64_t h = mix64(gpu::key_hash64(std::get<0>(t.getControlFields())));
             const unsigned long long lane = ((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes;
             const unsigned long long rel = ts > base ? ts - base : 0ull;
             k = (lane << (ts_bits + rank_bits)) | (rel << rank_bits) | (unsigned long long)src_rank[src];
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     auto lane_of = [&](uint32_t pos) -> uint32_t {
         const T t = pend[perm[pos]];
         if ((uint64_t)std::get<2>(t.getControlFields()) > W) return n_lanes;
-        const uint64_t h = mix64((uint64_t)std::get<0>(t.getControlFields()));
+        const uint64_t h = mix64(gpu::key_hash64(std::get<0>(t.getControlFields())));
         return (uint32_t)(((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes);
     };
     if (n == 0) {

@@ -277,10 +277,10 @@ __device__ __forceinline__ FFATStitched<R> ffat_stitch_wave(bool ok, uint32_t pa
     return o;
 }
 
-template <typename R, typename C>
+template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_stitch_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const FFATPartial<R>* parts, FFATPartial<R>* parts2,
-                            R* leaves, uint8_t* leaf_has, const unsigned long long* table, C comb) {
+                            R* leaves, uint8_t* leaf_has, KeyTableView<K> table, C comb) {
     const uint32_t total = ctl->total_units, nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         if (ok) pe = parts[2 * (size_t)hr.chunk_base + e];
         const FFATStitched<R> st = ffat_stitch_wave(ok, pe.pane, ok && pe.valid == 1, pe.val, comb);
         using key_t = decltype(cf_key(pe.val));
-        const key_t key = (key_t)table[hr.slot];
+        const key_t key = table.key_at(hr.slot);
         R* lv = leaves + (size_t)hr.leaf_base + (g.win_panes - 1);
         uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (g.win_panes - 1);
         FFATPartial<R>* mine = parts2 + 2 * (size_t)u;
@@ -336,11 +336,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-template <typename R, typename C>
+template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
                          const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint8_t* leaf_has, uint32_t* out_count, uint32_t* long_heads,
-                         uint32_t* n_long, const unsigned long long* table, FFATCounters* ctr, C comb, volatile uint32_t* disorder_seen = nullptr,
+                         uint32_t* n_long, KeyTableView<K> table, FFATCounters* ctr, C comb, volatile uint32_t* disorder_seen = nullptr,
                          uint32_t batch_no = 0) {
     const uint32_t nr = ctl->n_runs;
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         R* lv = leaves + (size_t)hr.leaf_base + (W - 1);  // lv[p] = pane P0 + p
         uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (W - 1);  // time-based: the pane received tuples (else it is a place holder)
         using key_t = decltype(cf_key(st.partial));
-        const key_t key = (key_t)table[hr.slot];
+        const key_t key = table.key_at(hr.slot);
         // the panes a window fired by this run can still need, in front of the new ones
         for (uint32_t j = (uint32_t)lane; j + 1 < W; j += WAVE) {
             const uint64_t back = (uint64_t)(W - 1 - j);  // pane P0 - back
@@ -551,17 +551,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-template <typename R, typename C>
+template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_windows_kernel(FFATGeometry g, const FFATHugeRun* runs, const FFATHugeCtl* ctl, const R* leaves, const R* pre, const R* suf, R* out,
-                             FFATCounters* ctr, const unsigned long long* table, C comb) {
+                             FFATCounters* ctr, KeyTableView<K> table, C comb) {
     const uint32_t nr = ctl->n_runs;
     const uint32_t W = g.win_panes;
     for (uint32_t r = 0; r < nr; r++) {
         const FFATHugeRun& hr = runs[r];
         if (hr.fallback || hr.nf == 0) continue;
         using key_t = decltype(cf_key(out[0]));
-        const key_t key = (key_t)table[hr.slot];
+        const key_t key = table.key_at(hr.slot);
         const R* lv = leaves + (size_t)hr.leaf_base + (W - 1);
         for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < hr.nf; w += gridDim.x * blockDim.x) {
             const uint64_t k = hr.first_lwid + w;

@@ -503,7 +503,29 @@ private:
     std::vector<Batch*> all_;
 };
 
+// WF_DEBUG_EVENTS=1: every release checks, before it records the slab's event, that the stream is alive, belongs to the
+// device the slab (and its event) were created on, and that this device is current in the calling thread - the three ways a
+// release could hand hipEventRecord a bad pair.  (Added to settle the origin of a fault seen under rocprofv3 with 8 lanes of
+// small batches, profiles/r2_small_batch: with the checks on, the run records no violation.)
+inline bool debug_events() {
+    static const bool on = [] {
+        const char* e = std::getenv("WF_DEBUG_EVENTS");
+        return e && std::atoi(e) != 0;
+    }();
+    return on;
+}
 inline void Batch::release(hipStream_t last_use_stream) {
+    if (debug_events()) {
+        int cur = -1;
+        hipDevice_t sdev = -1;
+        const hipError_t q = hipStreamQuery(last_use_stream);
+        if (q != hipSuccess && q != hipErrorNotReady) failwith(std::string("Batch::release: dead stream (") + hipGetErrorString(q) + ")");
+        WF_HIP_CHECK(hipGetDevice(&cur));
+        WF_HIP_CHECK(hipStreamGetDevice(last_use_stream, &sdev));
+        if ((int)sdev != device || cur != device)
+            failwith("Batch::release: slab of device " + std::to_string(device) + " released on a stream of device " + std::to_string((int)sdev) +
+                     " with device " + std::to_string(cur) + " current");
+    }
     ready.record(last_use_stream);
     pool->put(this);
 }

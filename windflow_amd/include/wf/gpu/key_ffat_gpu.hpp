@@ -421,6 +421,18 @@ __device__ __forceinline__ void fat_rebuild_range_wave(R* tree, uint32_t cap, ui
     }
 }
 
+// What closes a batch: the result count is clamped to the capacity and mirrored for the host, the run counters are reset for the
+// next batch (same stream).  ffat_finalize_kernel does it in a launch of its own; the long-run kernel - always the last of a
+// batch - does it in its last workgroup to finish (a ticket) when it is handed one of these, which saves the launch.
+struct FFATFinish {
+    BatchHeader* out_hdr = nullptr;  // nullptr: the caller launches ffat_finalize_kernel
+    uint32_t cap = 0;
+    volatile uint32_t* mirror = nullptr;
+    uint32_t* n_long = nullptr;
+    uint32_t* n_huge = nullptr;
+    uint32_t* ticket = nullptr;
+};
+
 // Long runs: one wave64 per run, exploiting the associativity of the combine.
 //  * all chunks: the 64 lanes gather and LIFT the next 64 tuples of the run together; lanes whose tuples
 //    fall in the same pane (CB) / quantum (TB) form a segment and an order-preserving segmented wave scan
@@ -439,7 +451,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
                             R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
                             const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb,
-                            volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0) {
+                            volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0, FFATFinish fin = FFATFinish{}) {
     extern __shared__ __align__(16) char ffat_smem[];
     const uint32_t n = hdr->count;
     const uint32_t runs = *n_long;
@@ -783,22 +795,37 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         if (lane == 0) states[slot] = st;
         wave_sync_lds();
     }
+    if (fin.out_hdr != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(fin.ticket, 1u) == gridDim.x - 1) {  // every other workgroup is done
+                __threadfence();
+                uint32_t c = __hip_atomic_load(&fin.out_hdr->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c > fin.cap) c = fin.cap;
+                fin.out_hdr->count = c;
+                *fin.mirror = c;
+                *fin.n_long = 0;
+                if (fin.n_huge) *fin.n_huge = 0;
+                *fin.ticket = 0;
+            }
+        }
+    }
 }
 
 // end of stream: one thread per table slot; completes what is open and emits the
 // remaining (incomplete) windows, as the CPU engine does (win_seqffat.hpp flush)
-template <typename R, typename C>
+template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_flush_kernel(const unsigned long long* table, uint32_t slot_lo, uint32_t slot_hi, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
+    ffat_flush_kernel(KeyTableView<K> table, uint32_t slot_lo, uint32_t slot_hi, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
                       FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, C comb) {
     for (uint32_t slot = slot_lo + blockIdx.x * blockDim.x + threadIdx.x; slot < slot_hi; slot += gridDim.x * blockDim.x) {
-        if (table[slot] == KEY_EMPTY) continue;
+        if (!table.occupied(slot)) continue;
         FFATKeyState<R> st = states[slot];
         if (!st.seen) continue;
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
-        // keys are stored as 64-bit values in the table
-        const auto key = (decltype(cf_key(st.partial)))table[slot];
+        const auto key = table.key_at(slot);
         if (!g.is_tb) {
             if (st.pcount > 0) {
                 ffat_complete_pane(st, tree, g, key, st.partial, comb, emit);
@@ -852,17 +879,14 @@ __global__ void ffat_finalize_kernel(BatchHeader* out_hdr, uint32_t cap, volatil
 namespace wf {
 namespace gpu {
 
-struct KeyOfTuple {
-    template <typename T>
-    __host__ __device__ uint64_t operator()(const T& t) const {
-        return (uint64_t)cf_key(t);
-    }
-};
-
 // The engine proper: owns the device state, processes device batches of tuples and
 // produces device batches of results.  Single stream, not thread safe.
 template <typename T, typename R, typename L, typename C>
 class KeyedFFATEngine {
+    using key_t = key_of_t<T>;
+    static_assert(is_device_key_v<key_t>, "Key_FFAT_GPU: keys must be integers or fixed-size keys (wf::FixedKey; primitives.hpp is_device_key_v)");
+    static_assert(std::is_same_v<key_t, key_of_t<R>>, "Key_FFAT_GPU: tuples and results must have the same key type");
+
 public:
     KeyedFFATEngine(L lift, C comb, uint64_t win, uint64_t slide, uint64_t delay, win_type_t type, size_t max_keys, size_t batch_capacity,
                     size_t out_capacity, int device, size_t pool_slabs, bool skip_gaps = false)
@@ -897,8 +921,7 @@ public:
         WF_HIP_CHECK(hipSetDevice(device_));
         // never the legacy (null) stream: its implicit dependencies would break stream captures running in other threads
         Stream init;
-        table_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_cap_ * sizeof(unsigned long long), init.get()));
+        table_.init(table_cap_, init.get());
         states_.resize(table_cap_);
         WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, table_cap_ * sizeof(FFATKeyState<R>), init.get()));
         trees_.resize((size_t)table_cap_ * 2 * g_.tree_cap);
@@ -914,8 +937,8 @@ public:
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(FFATCounters), init.get()));
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
-        n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
-        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
+        n_long_.resize(4);  // [0] long runs, [1] huge runs of the batch in flight, [2] ticket of the long-run kernel's workgroups
+        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 4 * sizeof(uint32_t), init.get()));
         // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones whose ring of open quanta is not enormous
         // (a long triggering delay keeps many quanta open: the scratch of a run spans all of them.  Sized for the 288 GB of an
         // MI355X: up to 2^18 open quanta per key as long as the scratch stays below 6 GB; beyond that the wave-per-run kernel)
@@ -1024,9 +1047,8 @@ private:
             // a batch that holds no key twice skips the sort (decided on the device: primitives.hpp DupProbe)
             const DupProbe probe = (presort || use_graphs_) ? DupProbe{} : dups_.probe(batch_no_);
             const SortGate gate = DupMonitor::gate(probe);
-            hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTuple>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyOfTuple{},
-                               out->header(), (uint32_t*)nullptr, probe);
+            hipLaunchKernelGGL((assign_slots_kernel<T, key_t>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
+                               table_.view(), slot_.data(), idx_.data(), &counters_.data()->table_full, out->header(), (uint32_t*)nullptr, probe);
             const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1,
                                                          disorder_.ts_bits(), g_.pane_len, disorder_.clamped(), batch_no_, s)
                                         : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s, gate);
@@ -1053,11 +1075,11 @@ private:
                                    huge_has_.data(), lift_, comb_);
                 const unsigned sgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (upper / WAVE / 32 + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
                 hipLaunchKernelGGL((ffat_huge_stitch_kernel<R, C>), dim3(sgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
-                                   huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), huge_has_.data(), table_.data(), comb_);
+                                   huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), huge_has_.data(), table_.view(), comb_);
                 const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
                                    acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
-                                   huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.data(), counters_.data(), comb_,
+                                   huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.view(), counters_.data(), comb_,
                                    disorder_.seen(), batch_no_);
                 const bool hgw = g_.win_panes > FFAT_HUGE_DIRECT_WIN;
                 if (hgw) {
@@ -1069,23 +1091,26 @@ private:
                 }
                 hipLaunchKernelGGL((ffat_huge_windows_kernel<R, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
                                    huge_leaves_.data(), hgw ? huge_pre_.data() : (const R*)nullptr, hgw ? huge_suf_.data() : (const R*)nullptr,
-                                   out->template data<R>(), counters_.data(), table_.data(), comb_);
+                                   out->template data<R>(), counters_.data(), table_.view(), comb_);
             }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
+            // (its last workgroup also closes the batch: no finalize launch)
+            const FFATFinish fin{out->header(), g_.out_cap, out->count_mirror, n_long_.data(), n_long_.data() + 1, n_long_.data() + 2};
             if (long_layout_.bulk == 2)
                 hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_, fin);
             else
                 hipLaunchKernelGGL((ffat_update_long_kernel<false, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_, fin);
+        } else {
+            hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
+                               n_long_.data() + 1);
         }
-        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
-                           n_long_.data() + 1);
     }
 
 public:
@@ -1104,7 +1129,7 @@ public:
         out->host_hdr = BatchHeader{};
         out->count_on_host = false;
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
-        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.data(), (uint32_t)lo, (uint32_t)hi,
+        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.view(), (uint32_t)lo, (uint32_t)hi,
                            states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_, out->template data<R>(), out->device_count_ptr(),
                            counters_.data(), comb_);
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
@@ -1126,7 +1151,7 @@ private:
     FFATGeometry g_{};
     size_t table_cap_ = 0, batch_cap_ = 0;
     int slot_bits_ = 0;
-    DeviceBuffer<unsigned long long> table_;
+    KeyTable<key_t> table_;
     DeviceBuffer<FFATKeyState<R>> states_;
     DeviceBuffer<R> trees_;
     DeviceBuffer<R> accs_;

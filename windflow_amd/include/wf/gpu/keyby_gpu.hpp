@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     dest_keys2_kernel(const BatchHeader* hdr, const T* data, uint32_t n_ranks, uint32_t n_lanes, uint32_t* dest, uint32_t* idx, KeyFn keyfn) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t h = mix64((uint64_t)keyfn(data[i]));
+        const uint64_t h = mix64(keyfn(data[i]));
         const uint32_t rank = (uint32_t)(((h >> HASH_SHIFT_RANKS) & 0xffffull) % n_ranks);
         const uint32_t lane = (uint32_t)(((h >> HASH_SHIFT_LANES) & 0xffffffull) % n_lanes);
         dest[i] = rank * n_lanes + lane;
@@ -224,13 +224,13 @@ public:
 
 private:
     struct KeyOfAny {
-        __host__ __device__ uint64_t operator()(const T& t) const { return (uint64_t)std::get<0>(t.getControlFields()); }
+        __host__ __device__ uint64_t operator()(const T& t) const { return key_hash64(std::get<0>(t.getControlFields())); }
     };
     // KeyBy: 24 bits of the key hash picked by hash_shift
     struct HashDest {
         uint32_t shift;
         __host__ __device__ uint64_t operator()(const T& t) const {
-            return (mix64((uint64_t)std::get<0>(t.getControlFields())) >> shift) & 0xffffffull;
+            return (mix64(key_hash64(std::get<0>(t.getControlFields()))) >> shift) & 0xffffffull;
         }
     };
     size_t n_dest_;

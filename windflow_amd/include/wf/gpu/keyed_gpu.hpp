@@ -320,14 +320,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
-struct KeyOfTupleK {
-    template <typename T>
-    __host__ __device__ uint64_t operator()(const T& t) const {
-        return (uint64_t)std::get<0>(t.getControlFields());
-    }
-};
-
 // device-resident keyed context: key table + sorter + state slab
+template <typename K>
 class KeyedContext {
 public:
     KeyedContext(size_t max_keys, size_t state_size, size_t batch_capacity, int device) : state_size_(state_size ? state_size : 1) {
@@ -338,8 +332,7 @@ public:
         table_cap_ = 2;
         while (table_cap_ < 2 * max_keys) table_cap_ <<= 1;
         while ((1ull << slot_bits_) < table_cap_) slot_bits_++;
-        table_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_.bytes(), init.get()));
+        table_.init(table_cap_, init.get());
         states_.resize(table_cap_ * state_size_);
         WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, states_.bytes(), init.get()));
         slot_.resize(batch_capacity);
@@ -356,8 +349,8 @@ public:
     template <typename T>
     RadixSorter::Sorted group(Batch* in, hipStream_t s, uint64_t& kernels) {
         const size_t upper = std::max<size_t>(1, in->count_on_host ? in->host_hdr.count : in->capacity);
-        hipLaunchKernelGGL((assign_slots_kernel<T, KeyOfTupleK>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(),
-                           in->template data<T>(), table_.data(), (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), full_.data(), KeyOfTupleK{},
+        hipLaunchKernelGGL((assign_slots_kernel<T, K>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(),
+                           in->template data<T>(), table_.view(), slot_.data(), idx_.data(), full_.data(),
                            (BatchHeader*)nullptr, n_long_.data());  // also resets the long-run counter of the batch
         kernels += 1 + sorter_.kernels_per_sort(slot_bits_ + 1);
         return sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s);
@@ -387,7 +380,7 @@ public:
 private:
     size_t state_size_, table_cap_ = 0, lds_budget_ = 60 * 1024;
     int slot_bits_ = 0;
-    DeviceBuffer<unsigned long long> table_;
+    KeyTable<K> table_;
     DeviceBuffer<char> states_;
     DeviceBuffer<uint32_t> slot_, idx_, full_, long_heads_, n_long_;
     RadixSorter sorter_;
@@ -413,7 +406,7 @@ protected:
     void process_device(gpu::Batch* d) override {
         hipStream_t s = this->stream();
         if (!ctx_) {
-            ctx_.reset(new gpu::KeyedContext(kcfg_.max_keys, kcfg_.state_size, d->capacity, this->cfg_.gpu_id));
+            ctx_.reset(new gpu::KeyedContext<key_of_t<tuple_t>>(kcfg_.max_keys, kcfg_.state_size, d->capacity, this->cfg_.gpu_id));
             batch_cap_ = d->capacity;
         }
         if (d->capacity > batch_cap_) gpu::failwith("keyed GPU operator: a batch larger than the first one received");
@@ -498,7 +491,7 @@ private:
     F func_;
     KeyedGPUConfig kcfg_;
     size_t batch_cap_ = 0;
-    std::unique_ptr<gpu::KeyedContext> ctx_;
+    std::unique_ptr<gpu::KeyedContext<key_of_t<tuple_t>>> ctx_;
     std::unique_ptr<gpu::BatchPool> out_pool_;
     gpu::DeviceBuffer<uint8_t> flags_;
     gpu::DeviceBuffer<unsigned long long> ws_;

@@ -16,6 +16,17 @@
 
 namespace wf {
 
+// A device functor that reads side tables in HBM (the lookup table of the reference's stateless benchmark,
+// gpu_map_stateless.cpp:369-386; the campaign table of the Yahoo benchmark) may define a host-only
+//     void bind_device(int gpu_id)
+// which every replica calls on ITS copy of the functor before the first batch, on the thread and device it runs on: the place
+// to upload the table to that GPU and store the device pointers in the functor (replicas of one operator can sit on different
+// GPUs: withGPUPlacement).
+template <typename F, typename = void>
+struct has_bind_device : std::false_type {};
+template <typename F>
+struct has_bind_device<F, std::void_t<decltype(std::declval<F&>().bind_device(0))>> : std::true_type {};
+
 template <typename tuple_t, typename result_t, typename F>
 class MapGPU_Node : public GPU_Replica<tuple_t> {
 public:
@@ -25,6 +36,9 @@ public:
         : GPU_Replica<tuple_t>(cfg, in_kind, std::move(name), par, idx, std::move(closing), std::move(hub)), func_(std::move(func)) {}
 
 protected:
+    void gpu_init() override {
+        if constexpr (has_bind_device<F>::value) func_.bind_device(this->cfg_.gpu_id);
+    }
     void process_device(gpu::Batch* d) override {
         const size_t upper = d->count_on_host ? d->host_hdr.count : d->capacity;
         const unsigned grid = gpu::grid_for(upper);

@@ -21,6 +21,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <tuple>
+#include <type_traits>
+#include <utility>
 
 #include "hip_utils.hpp"
 #include "kernels_basic.hpp"
@@ -171,6 +173,128 @@ __device__ __forceinline__ uint32_t key_table_slot(unsigned long long* table, ui
     return 0xffffffffu;
 }
 
+// ---- keys of any device-friendly type ------------------------------------------------------------------------------------
+// A key is an integer (the table word IS the key) or a fixed-size value type with hash() and == (basic.hpp FixedKey; the
+// reference's GPU programs key by std::string, src/mp_test_gpu/mp_common_string.hpp:44-84): then the table word is a 64-bit
+// fingerprint of the key and the key itself lives in a slab next to the table; a slot is claimed with one CAS on the
+// fingerprint, the winner publishes the key (`ready`), everybody else compares the key, so two keys with the same fingerprint
+// simply occupy two slots.
+template <typename K>
+struct is_fixed_key {
+    template <typename X>
+    static auto test(int) -> decltype((uint64_t)std::declval<const X&>().hash(), (bool)(std::declval<const X&>() == std::declval<const X&>()), std::true_type{});
+    template <typename>
+    static std::false_type test(...);
+    static constexpr bool value = decltype(test<K>(0))::value && std::is_trivially_copyable_v<K> && sizeof(K) <= 32 && sizeof(K) % 4 == 0;
+};
+template <typename K>
+constexpr bool is_device_key_v = std::is_integral_v<K> || is_fixed_key<K>::value;
+
+// what std::hash gives for the key on the host (the identity for integers): window assignment and routing derive from it
+template <typename K>
+__host__ __device__ __forceinline__ uint64_t key_hash64(const K& k) {
+    if constexpr (std::is_integral_v<K>)
+        return (uint64_t)k;
+    else
+        return (uint64_t)k.hash();
+}
+template <typename T>
+__host__ __device__ __forceinline__ auto tuple_key(const T& t) {
+    return std::get<0>(t.getControlFields());
+}
+
+template <typename K>
+struct KeyTableView {
+    static constexpr bool direct = std::is_integral_v<K>;
+    unsigned long long* words = nullptr;  // direct: the keys; otherwise fingerprints
+    K* keys = nullptr;                    // fixed-size keys only
+    uint32_t* ready = nullptr;            // fixed-size keys only: the key of the slot has been published
+    uint32_t mask = 0;
+
+    // slot of `key`, inserting it if absent; 0xffffffff: table full (or, for integers, the reserved key 2^64-1)
+    __device__ __forceinline__ uint32_t slot_of(const K& key) const {
+        if constexpr (direct) {
+            return key_table_slot(words, mask, (unsigned long long)key);
+        } else {
+            unsigned long long fp = mix64(key_hash64(key));
+            if (fp == KEY_EMPTY) fp = 0;
+            uint32_t h = (uint32_t)fp & mask;
+            uint32_t probes = 0;
+            // (a lane that finds the fingerprint of a key not yet published goes round the loop again instead of spinning: the
+            // publisher may be a lane of the same wave, which completes its branch of the iteration before the next one begins)
+            while (probes <= mask) {
+                unsigned long long cur = __hip_atomic_load(&words[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == KEY_EMPTY) {
+                    const unsigned long long prev = atomicCAS(&words[h], KEY_EMPTY, fp);
+                    if (prev == KEY_EMPTY) {
+                        keys[h] = key;
+                        __hip_atomic_store(&ready[h], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        return h;
+                    }
+                    cur = prev;
+                }
+                if (cur == fp) {
+                    if (__hip_atomic_load(&ready[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) continue;
+                    if (keys[h] == key) return h;
+                }
+                h = (h + 1) & mask;
+                probes++;
+            }
+            return 0xffffffffu;
+        }
+    }
+    __device__ __forceinline__ bool occupied(uint32_t slot) const { return words[slot] != KEY_EMPTY; }
+    __device__ __forceinline__ K key_at(uint32_t slot) const {
+        if constexpr (direct)
+            return (K)words[slot];
+        else
+            return keys[slot];
+    }
+    // the key's host-side hash code (the window a replica starts at depends on it)
+    __device__ __forceinline__ uint64_t hash_at(uint32_t slot) const {
+        if constexpr (direct)
+            return (uint64_t)words[slot];
+        else
+            return key_hash64(keys[slot]);
+    }
+};
+
+template <typename K>
+class KeyTable {
+    static_assert(is_device_key_v<K>, "keys of GPU operators: an integer, or a trivially copyable type of at most 32 bytes with hash() and == (wf::FixedKey)");
+
+public:
+    void init(size_t capacity, hipStream_t s) {
+        cap_ = capacity;
+        words_.resize(capacity);
+        WF_HIP_CHECK(hipMemsetAsync(words_.data(), 0xff, words_.bytes(), s));
+        if constexpr (!KeyTableView<K>::direct) {
+            keys_.resize(capacity);
+            ready_.resize(capacity);
+            WF_HIP_CHECK(hipMemsetAsync(keys_.data(), 0, keys_.bytes(), s));
+            WF_HIP_CHECK(hipMemsetAsync(ready_.data(), 0, ready_.bytes(), s));
+        }
+    }
+    KeyTableView<K> view() const {
+        KeyTableView<K> v;
+        v.words = words_.data();
+        if constexpr (!KeyTableView<K>::direct) {
+            v.keys = keys_.data();
+            v.ready = ready_.data();
+        }
+        v.mask = (uint32_t)(cap_ - 1);
+        return v;
+    }
+    size_t capacity() const { return cap_; }
+    size_t bytes() const { return words_.bytes() + keys_.bytes() + ready_.bytes(); }
+
+private:
+    size_t cap_ = 0;
+    DeviceBuffer<unsigned long long> words_;
+    DeviceBuffer<K> keys_;
+    DeviceBuffer<uint32_t> ready_;
+};
+
 // ---- batches in which no key occurs twice need no sort -------------------------------------------------------------
 // The keyed engines sort (slot, index) pairs so that the tuples of a key become a run in arrival order.  A batch that holds
 // at most one tuple of every key (many keys, round-robin or sparse arrivals: the flagship stream) is already "a run per
@@ -203,13 +327,13 @@ struct SortedSel {
 };
 constexpr uint32_t DUP_LDS_SLOTS = 1024;
 
-// slot[i] = slot of tuple i's key; idx[i] = i.  KeyFn: uint64_t(const T&)
+// slot[i] = slot of tuple i's key; idx[i] = i.
 // First kernel of a keyed batch: it also clears what the later kernels of the batch accumulate into (the header
 // of the output batch, a counter word) - one launch instead of a memset each.
-template <typename T, typename KeyFn>
+template <typename T, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    assign_slots_kernel(const BatchHeader* hdr, const T* data, unsigned long long* table, uint32_t mask, uint32_t* slot, uint32_t* idx,
-                        uint32_t* n_failed, KeyFn keyfn, BatchHeader* clear_hdr, uint32_t* clear_word, DupProbe probe = DupProbe{}) {
+    assign_slots_kernel(const BatchHeader* hdr, const T* data, KeyTableView<K> table, uint32_t* slot, uint32_t* idx,
+                        uint32_t* n_failed, BatchHeader* clear_hdr, uint32_t* clear_word, DupProbe probe = DupProbe{}) {
     __shared__ uint32_t s_seen[DUP_LDS_SLOTS];
     const uint32_t n = hdr->count;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(BatchHeader) / sizeof(uint64_t)) {
@@ -223,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
     bool dup = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t s = key_table_slot(table, mask, (unsigned long long)keyfn(data[i]));
+        const uint32_t s = table.slot_of((K)tuple_key(data[i]));
         if (s == 0xffffffffu) atomicAdd(n_failed, 1u);
         slot[i] = s;
         idx[i] = i;
@@ -556,6 +680,49 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// ---- small batches: the whole sort in ONE workgroup ------------------------------------------------------------------------
+// A pass of the radix sort is three launches, a sort two or three passes: for a batch of a few thousand pairs that is 6-9
+// launches of a few microseconds each, on a stream whose other kernels take as long - latency-oriented pipelines (the
+// reference's own batch of 10 000, results.org:126) spend their time launching.  Up to SMALL_SORT_MAX pairs are sorted by one
+// 1024-thread workgroup instead: the pairs become 64-bit words (key << 32 | position) in LDS - 16 Ki of them are 128 KB of the
+// 160 KB a gfx950 CU has -, a bitonic network orders them (the position in the low half makes the order stable and the words
+// distinct), and the values are gathered by position on the way out.
+constexpr uint32_t SMALL_SORT_MAX = 16384;
+constexpr int SMALL_SORT_THREADS = 1024;
+__global__ void __launch_bounds__(SMALL_SORT_THREADS)
+    small_sort_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, const uint32_t* n_ptr, uint32_t n_pow2,
+                      SortGate gate) {
+    extern __shared__ __align__(16) unsigned long long ss_words[];
+    if (gate.closed()) return;
+    uint32_t n = *n_ptr;
+    if (n > n_pow2) n = n_pow2;
+    // the network only has to cover the smallest power of two that holds the batch
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += SMALL_SORT_THREADS)
+        ss_words[i] = i < n ? ((unsigned long long)keys_in[i] << 32) | (unsigned long long)i : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (N >> 1); t += SMALL_SORT_THREADS) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the lower element of pair t at distance j
+                const unsigned long long a = ss_words[i], b = ss_words[i + j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    ss_words[i] = b;
+                    ss_words[i + j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += SMALL_SORT_THREADS) {
+        const unsigned long long w = ss_words[i];
+        keys_out[i] = (uint32_t)(w >> 32);
+        vals_out[i] = vals_in[(uint32_t)(w & 0xffffffffull)];
+    }
+}
+
 // Workspace + driver for sorting up to `capacity` pairs.  `bits` = number of
 // significant key bits.  n is read from device memory so a data-dependent count
 // never has to come back to the host.
@@ -563,6 +730,14 @@ class RadixSorter {
 public:
     void reserve(size_t capacity) {
         if (capacity <= cap_) return;
+        if (cap_ == 0) {
+            // the one-workgroup sort keeps the whole batch in LDS: as many pairs as the device's LDS holds (WF_SMALL_SORT=0: off)
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            small_lds_pairs_ = max_lds_per_block(dev) / sizeof(unsigned long long);
+            if (const char* e = std::getenv("WF_SMALL_SORT")) small_sort_ = std::atoi(e) != 0;
+            if (small_sort_) allow_dynamic_lds(small_sort_kernel, std::min<size_t>(small_lds_pairs_, SMALL_SORT_MAX) * sizeof(unsigned long long));
+        }
         cap_ = capacity;
         tiles_ = (capacity + RS_TILE - 1) / RS_TILE;
         keys_tmp_.resize(capacity);
@@ -594,6 +769,13 @@ public:
         if (tiles == 0) return {kin, vin};
         uint32_t* kout = keys_tmp_.data();
         uint32_t* vout = vals_tmp_.data();
+        if (small_sort_ && n_upper <= (size_t)SMALL_SORT_MAX && n_upper <= small_lds_pairs_) {
+            uint32_t n_pow2 = 2;
+            while (n_pow2 < n_upper) n_pow2 <<= 1;
+            hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(SMALL_SORT_THREADS), (size_t)n_pow2 * sizeof(unsigned long long), s, kin, vin, kout, vout,
+                               n_dev, n_pow2, gate);
+            return {kout, vout};
+        }
         const int d = digit_bits(bits), n_pass = passes(bits);
         // small batches (latency-oriented pipelines) are launch-bound: two launches per pass instead of three
         const bool fused = tiles <= FUSE_TILES;
@@ -625,12 +807,13 @@ public:
         }
         return {kin, vin};
     }
-    int kernels_per_sort(int bits) const { return 3 * passes(bits); }  // upper bound (2 per pass for small batches)
+    int kernels_per_sort(int bits) const { return 3 * passes(bits); }  // upper bound (2 per pass for small batches, 1 for the smallest)
     // batches of at most this many tiles (2048 pairs each) skip the scan kernel: the scatter blocks read the raw counts
     static constexpr uint32_t FUSE_TILES = 16;
 
 private:
-    size_t cap_ = 0, tiles_ = 0;
+    size_t cap_ = 0, tiles_ = 0, small_lds_pairs_ = 0;
+    bool small_sort_ = true;
     DeviceBuffer<uint32_t> keys_tmp_, vals_tmp_, hist_, bin_totals_;
 };
 

@@ -106,7 +106,8 @@ struct WinGeometry {
 struct WinAssignD {
     uint64_t first_gwid_key, initial_id, gwid_stride, a_inner;
 };
-// SURVEY.md A.4 (reference win_seq.hpp:328-336); keys are integral, std::hash of an integer is the identity
+// SURVEY.md A.4 (reference win_seq.hpp:328-336); `hashcode` is what std::hash gives on the host (primitives.hpp key_hash64:
+// the identity for integers, FixedKey::hash() for fixed-size keys)
 __host__ __device__ inline WinAssignD win_assign(const WinGeometry& g, uint64_t hashcode) {
     WinAssignD a;
     a.a_inner = (g.id_inner + g.n_inner - (hashcode % g.n_inner)) % g.n_inner;
@@ -200,9 +201,9 @@ __device__ __forceinline__ uint32_t win_lower_bound(const T* seg, uint32_t n, ui
 constexpr uint32_t WB_QUIET_RUN = 16;       // longest run appended in place
 constexpr uint32_t WB_NO_RUN = 0xffffffffu;  // WinKeyState::cur_run of a key whose run was appended
 
-template <typename T>
+template <typename T, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_runs_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, const unsigned long long* table,
+    wb_runs_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, KeyTableView<K> table,
                    WinKeyState* states, WinRun* runs, uint32_t* work_len, T* carry, WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t quiet_ok,
                    uint32_t* unsorted_stamp, uint32_t batch_no, volatile uint32_t* disorder_seen) {
     const uint32_t n = hdr->count;
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             atomicAdd(&ctr->table_full, len);
             continue;
         }
-        const WinAssignD wa = win_assign(g, (uint64_t)table[slot]);
+        const WinAssignD wa = win_assign(g, table.hash_at(slot));
         if (quiet_ok && len <= WB_QUIET_RUN && st.carry_len + len <= g.carry_cap && g.win >= g.slide) {
             // in order (also against what is carried), not late, and no window of the key ends with these tuples?
             T* area = carry + (size_t)st.dense * g.carry_cap;
@@ -419,11 +420,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) wb_sortfix_kernel(WinRun* runs,
 }
 
 // ---- 5. windows fired by the batch ---------------------------------------------------------------
+template <typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_plan_kernel(const unsigned long long* table, const WinRun* runs, uint32_t* n_fire, const WinCtl* ctl, WinGeometry g) {
+    wb_plan_kernel(KeyTableView<K> table, const WinRun* runs, uint32_t* n_fire, const WinCtl* ctl, WinGeometry g) {
     const uint32_t n_runs = ctl->n_runs;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += gridDim.x * blockDim.x) {
-        const WinAssignD wa = win_assign(g, (uint64_t)table[runs[r].slot]);
+        const WinAssignD wa = win_assign(g, table.hash_at(runs[r].slot));
         const uint64_t upto = win_fired_upto(g, wa.initial_id, runs[r].max_ord);
         const uint64_t nf = upto > runs[r].first_lwid ? upto - runs[r].first_lwid : 0;
         // windows beyond the capacity of the output batch are deferred anyway; the clamp also keeps the 32-bit scan exact
@@ -435,17 +437,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 // end of stream: every window opened so far fires, at most `quota` per key and round; the "runs" are the slots of
 // [slot_lo, slot_hi) and their segments are the carry areas themselves
+template <typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_flush_plan_kernel(const unsigned long long* table, uint32_t slot_lo, uint32_t slot_hi, WinKeyState* states, WinRun* runs, uint32_t* n_fire,
+    wb_flush_plan_kernel(KeyTableView<K> table, uint32_t slot_lo, uint32_t slot_hi, WinKeyState* states, WinRun* runs, uint32_t* n_fire,
                          WinCtl* ctl, WinGeometry g, uint32_t quota) {
     for (uint32_t slot = slot_lo + blockIdx.x * blockDim.x + threadIdx.x; slot < slot_hi; slot += gridDim.x * blockDim.x) {
         const uint32_t r = slot - slot_lo;
         WinRun run{};
         run.slot = slot;
         uint32_t nf32 = 0;
-        if (table[slot] != KEY_EMPTY && (states[slot].flags & 1u) && states[slot].dense < g.max_keys) {
+        if (table.occupied(slot) && (states[slot].flags & 1u) && states[slot].dense < g.max_keys) {
             const WinKeyState st = states[slot];
-            const WinAssignD wa = win_assign(g, (uint64_t)table[slot]);
+            const WinAssignD wa = win_assign(g, table.hash_at(slot));
             const uint64_t upto = win_opened_upto(g, wa.initial_id, st.max_ord);
             uint64_t nf = upto > st.next_lwid ? upto - st.next_lwid : 0;
             if (nf > quota) {
@@ -469,9 +472,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 // ---- 6. window descriptors -----------------------------------------------------------------------
 // EMIT_BASE: where the emit counter of the key stood before these windows (states are only updated by the commit)
-template <typename T, typename R>
+template <typename T, typename R, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_desc_kernel(const unsigned long long* table, const WinKeyState* states, const WinRun* runs, const uint32_t* win_off, const uint32_t* n_fire,
+    wb_desc_kernel(KeyTableView<K> table, const WinKeyState* states, const WinRun* runs, const uint32_t* win_off, const uint32_t* n_fire,
                    const T* base, WinDesc* desc, R* out, const WinCtl* ctl, WinGeometry g, uint32_t flushing) {
     const uint32_t n_runs = ctl->n_runs;
     uint32_t n_win = ctl->win_total;
@@ -490,8 +493,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         const WinRun run = runs[r];
         const uint64_t k = w - win_off[r];
         const uint64_t lwid = run.first_lwid + k;
-        const unsigned long long key64 = table[run.slot];
-        const WinAssignD wa = win_assign(g, (uint64_t)key64);
+        const WinAssignD wa = win_assign(g, table.hash_at(run.slot));
         const uint64_t start = wa.initial_id + lwid * g.slide, end = start + g.win;
         const T* seg = base + run.seg_off;
         uint32_t p0, p1;
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         else if (g.role == (uint32_t)PLQ)
             id = wa.a_inner + emitted * g.n_inner;
         R res{};
-        res.setControlFields((decltype(cf_key(res)))key64, id, ts);
+        res.setControlFields((decltype(cf_key(res)))table.key_at(run.slot), id, ts);
         out[w] = res;
     }
 }
@@ -574,13 +576,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 constexpr int WB_TILE_THREADS = 1024;
 constexpr int WB_TILE_WAVES = WB_TILE_THREADS / WAVE;
 constexpr unsigned WB_TILE_GRID = 1024;
-constexpr size_t WB_TILE_STATIC_LDS = 256;  // the kernel's own words, kept out of the dynamic budget
+constexpr size_t WB_TILE_STATIC_LDS = 0;  // the kernel keeps no static LDS (see s_lohi)
 template <typename T, typename R, typename F>
 __global__ void __launch_bounds__(WB_TILE_THREADS)
     wb_eval_tile_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, uint32_t group, uint32_t tile_tuples,
                         uint32_t by_wave, char* scratch, size_t scratch_size, F f) {
     extern __shared__ __align__(16) char wb_tile_smem[];
-    __shared__ unsigned long long s_lo, s_hi;
+    // the bounds of the group's span are reduced in the first 16 bytes of the tile itself, before the span is staged over
+    // them: the kernel has no static LDS, so a window of exactly the device's LDS size (4096 tuples of 40 bytes in 160 KB) fits
+    unsigned long long* s_lohi = reinterpret_cast<unsigned long long*>(wb_tile_smem);
     // staged in the widest words the tuple type is aligned to
     typedef std::conditional_t<alignof(T) % 8 == 0, uint64_t, std::conditional_t<alignof(T) % 4 == 0, uint32_t, uint8_t>> raw_word_t;
     typedef raw_word_t __attribute__((may_alias)) word_t;
@@ -596,19 +600,20 @@ __global__ void __launch_bounds__(WB_TILE_THREADS)
         const uint32_t w0 = gi * group;
         const uint32_t cnt = n_win - w0 < group ? n_win - w0 : group;
         if (threadIdx.x == 0) {
-            s_lo = ~0ull;
-            s_hi = 0ull;
+            s_lohi[0] = ~0ull;
+            s_lohi[1] = 0ull;
         }
         __syncthreads();
         WinDesc d{};
         const bool mine = k < cnt;
         if (mine) {
             d = desc[w0 + k];
-            atomicMin(&s_lo, (unsigned long long)d.off);
-            atomicMax(&s_hi, (unsigned long long)(d.off + d.len));
+            atomicMin(&s_lohi[0], (unsigned long long)d.off);
+            atomicMax(&s_lohi[1], (unsigned long long)(d.off + d.len));
         }
         __syncthreads();
-        const uint64_t lo = s_lo, hi = s_hi;
+        const uint64_t lo = s_lohi[0], hi = s_lohi[1];
+        __syncthreads();  // everyone has the bounds: the tile may be written
         const bool fits = hi >= lo && hi - lo <= (uint64_t)tile_tuples;
         if (fits) {
             const word_t* src = reinterpret_cast<const word_t*>(base + lo);
@@ -756,9 +761,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 // each, so that a few long carries (few keys, long windows) spread over the whole chip; wave 0 of a run writes its state.
 constexpr uint32_t WB_COMMIT_CHUNK = 512;  // 8-byte words per wave
 
-template <typename T>
+template <typename T, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_commit_kernel(const unsigned long long* table, WinKeyState* states, const WinRun* runs, const uint32_t* n_fire, const uint32_t* win_off,
+    wb_commit_kernel(KeyTableView<K> table, WinKeyState* states, const WinRun* runs, const uint32_t* n_fire, const uint32_t* win_off,
                      const T* work, T* carry, const WinCtl* ctl, WinCounters* ctr, WinGeometry g, uint32_t chunks) {
     using W = std::conditional_t<sizeof(T) % 8 == 0 && alignof(T) % 8 == 0, uint64_t,
                                  std::conditional_t<sizeof(T) % 4 == 0 && alignof(T) % 4 == 0, uint32_t, unsigned char>>;
@@ -770,7 +775,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     for (uint64_t u = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); u < units; u += waves_total) {
         const uint32_t r = (uint32_t)(u / chunks), c = (uint32_t)(u % chunks);
         const WinRun run = runs[r];
-        const WinAssignD wa = win_assign(g, (uint64_t)table[run.slot]);
+        const WinAssignD wa = win_assign(g, table.hash_at(run.slot));
         // windows that did not fit the output batch are not fired now: they stay open (their tuples are carried) and fire
         // with the next batch that holds the key, or at end of stream
         const uint32_t fired = win_off[r] >= g.out_cap ? 0u : (n_fire[r] < g.out_cap - win_off[r] ? n_fire[r] : g.out_cap - win_off[r]);
@@ -825,13 +830,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 
 // end-of-stream markers: they only advance the state of their key
-template <typename T>
+template <typename T, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_markers_kernel(const BatchHeader* hdr, const T* data, unsigned long long* table, uint32_t mask, WinKeyState* states, WinCtl* ctl,
+    wb_markers_kernel(const BatchHeader* hdr, const T* data, KeyTableView<K> table, WinKeyState* states, WinCtl* ctl,
                       WinCounters* ctr, WinGeometry g) {
     const uint32_t n = hdr->count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = key_table_slot(table, mask, (unsigned long long)cf_key(data[i]));
+        const uint32_t slot = table.slot_of(cf_key(data[i]));
         if (slot == 0xffffffffu) {
             atomicAdd(&ctr->table_full, 1u);
             continue;
@@ -872,7 +877,9 @@ struct WinGPUOptions {
 // Single stream, not thread safe.
 template <typename T, typename R, typename F>
 class WinBatchEngine {
-    static_assert(std::is_integral_v<key_of_t<T>>, "GPU window operators need integral keys (the key table stores them as 64-bit words)");
+    using key_t = key_of_t<T>;
+    static_assert(is_device_key_v<key_t>, "GPU window operators: keys must be integers or fixed-size keys (wf::FixedKey; primitives.hpp is_device_key_v)");
+    static_assert(std::is_same_v<key_t, key_of_t<R>>, "GPU window operators: tuples and results must have the same key type");
     static_assert(std::is_trivially_copyable_v<T> && std::is_trivially_copyable_v<R>, "GPU window operators move tuples and results as raw bytes");
 
 public:
@@ -916,8 +923,7 @@ public:
             failwith("GPU window operator: " + std::to_string(need >> 20) + " MiB of device memory needed for " + std::to_string(g_.max_keys) +
                      " keys x " + std::to_string(g_.carry_cap) + " carried tuples; lower withMaxKeys / withArchiveCapacity");
         Stream init;  // never the legacy stream
-        table_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemsetAsync(table_.data(), 0xff, table_.bytes(), init.get()));
+        table_.init(table_cap_, init.get());
         states_.resize(table_cap_);
         WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, states_.bytes(), init.get()));
         unsorted_stamp_.resize(table_cap_);
@@ -958,14 +964,31 @@ public:
         // memory by itself.
         {
             const size_t lds = max_lds_per_block(device_);
-            const uint64_t tile_max = lds > WB_TILE_STATIC_LDS ? (lds - WB_TILE_STATIC_LDS) / sizeof(T) : 0;
+            // (whatever static LDS the compiler gave the kernel after all is taken off the budget)
+            size_t fixed = WB_TILE_STATIC_LDS;
+            if constexpr (!is_map_reduce_t<F>::value && !is_wave_reduce_t<F>::value) {
+                hipFuncAttributes fa{};
+                if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&wb_eval_tile_kernel<T, R, F>)) == hipSuccess) fixed = fa.sharedSizeBytes;
+            }
+            const uint64_t tile_max = lds > fixed ? (lds - fixed) / sizeof(T) : 0;
             uint64_t w = g_.win, sl = g_.slide;
             if (g_.is_tb && w > g_.carry_cap) {
                 sl = std::max<uint64_t>(1, sl * g_.carry_cap / w);
                 w = g_.carry_cap;
             }
             if (w <= tile_max) {
-                tile_group_ = (uint32_t)std::min<uint64_t>(WB_TILE_THREADS, (tile_max - w) / sl + 1);
+                // As many windows per workgroup as the LDS holds - but no more than it takes to give every CU two workgroups of
+                // the windows a full batch fires: the evaluation of a batch lasts as long as ONE workgroup needs (stage its
+                // span, then the sequential loop of the functor), so few fat workgroups on a few CUs are slower than many
+                // lean ones (measured, one key, win 1024 / slide 128: 25 windows x 41 workgroups 49 us, 5 x 205: 25 us).
+                int cus = 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || cus <= 0) cus = 256;
+                const uint64_t by_lds = (tile_max - w) / sl + 1;
+                const uint64_t per_batch = std::max<uint64_t>(1, batch_cap_ / std::max<uint64_t>(1, g_.slide));  // windows a full batch fires (count-based)
+                const uint64_t balanced = std::max<uint64_t>(4, per_batch / (2 * (uint64_t)cus));
+                tile_group_ = (uint32_t)std::min<uint64_t>(WB_TILE_THREADS, std::min(by_lds, g_.is_tb ? by_lds : balanced));
+                tile_cus_ = (uint32_t)cus;
+                tile_lds_total_ = lds;
                 // count-based windows: exactly the span of the group; time-based ones: everything there is (the estimate is loose)
                 tile_tuples_ = (uint32_t)(g_.is_tb ? tile_max : std::min<uint64_t>(tile_max, (uint64_t)(tile_group_ - 1) * sl + w));
                 // lanes per busy LDS bank under the two thread -> window maps (see the kernel)
@@ -1023,16 +1046,15 @@ public:
         const DupProbe probe = presort ? DupProbe{} : dups_.probe(batch_no_);
         const SortGate gate = DupMonitor::gate(probe);
         // also clears the header of the output batch and the run counter
-        hipLaunchKernelGGL((assign_slots_kernel<T, KeyFn>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.data(),
-                           (uint32_t)(table_cap_ - 1), slot_.data(), idx_.data(), &counters_.data()->table_full, KeyFn{}, out->header(),
-                           &ctl_.data()->n_runs, probe);
+        hipLaunchKernelGGL((assign_slots_kernel<T, key_t>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.view(),
+                           slot_.data(), idx_.data(), &counters_.data()->table_full, out->header(), &ctl_.data()->n_runs, probe);
         const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1, 32,
                                                      1, disorder_.clamped(), batch_no_, s)
                                     : sorter_.sort(slot_.data(), idx_.data(), in->device_count_ptr(), upper, slot_bits_ + 1, s, gate);
         const SortedSel sel{sorted.keys, sorted.vals, slot_.data(), idx_.data(), gate};
         if (presort) presorted_batches_++;
         hipLaunchKernelGGL((wb_runs_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sel,
-                           table_.data(), states_.data(), runs_.data(), work_len_.data(), carry_.data(), ctl_.data(), counters_.data(), g_,
+                           table_.view(), states_.data(), runs_.data(), work_len_.data(), carry_.data(), ctl_.data(), counters_.data(), g_,
                            quiet_runs_ ? 1u : 0u, unsorted_stamp_.data(), batch_no_, disorder_.seen());
         exclusive_scan_u32(work_len_.data(), work_off_.data(), runs_upper, &ctl_.data()->work_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
         hipLaunchKernelGGL((wb_gather_kernel<T>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sel,
@@ -1040,14 +1062,14 @@ public:
                            unsorted_stamp_.data(), batch_no_);
         if (!g_.renumber)
             hipLaunchKernelGGL((wb_sortfix_kernel<T>), dim3(rgrid), dim3(BLOCK_THREADS), 0, s, runs_.data(), work_.data(), ctl_.data(), g_);
-        hipLaunchKernelGGL(wb_plan_kernel, dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), runs_.data(), n_fire_.data(), ctl_.data(), g_);
+        hipLaunchKernelGGL((wb_plan_kernel<key_t>), dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.view(), runs_.data(), n_fire_.data(), ctl_.data(), g_);
         exclusive_scan_u32(n_fire_.data(), win_off_.data(), runs_upper, &ctl_.data()->win_total, scan_ws_.data(), s, &ctl_.data()->n_runs);
         evaluate(work_.data(), out, s, 0);
         {
             const size_t wpt = (sizeof(T) + 7) / 8;
             const uint32_t chunks = (uint32_t)std::max<size_t>(1, (g_.carry_cap * wpt + WB_COMMIT_CHUNK - 1) / WB_COMMIT_CHUNK);
             const unsigned cgrid = (unsigned)std::min<size_t>(4096, std::max<size_t>(1, (runs_upper * chunks + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE)));
-            hipLaunchKernelGGL((wb_commit_kernel<T>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), states_.data(), runs_.data(), n_fire_.data(),
+            hipLaunchKernelGGL((wb_commit_kernel<T>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, table_.view(), states_.data(), runs_.data(), n_fire_.data(),
                                win_off_.data(), work_.data(), carry_.data(), ctl_.data(), counters_.data(), g_, chunks);
         }
         hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data());
@@ -1059,8 +1081,8 @@ public:
     void apply_markers(Batch* in, hipStream_t s, uint64_t& kernels) {
         const size_t upper = in->count_on_host ? in->host_hdr.count : in->capacity;
         if (upper == 0) return;
-        hipLaunchKernelGGL((wb_markers_kernel<T>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.data(),
-                           (uint32_t)(table_cap_ - 1), states_.data(), ctl_.data(), counters_.data(), g_);
+        hipLaunchKernelGGL((wb_markers_kernel<T>), dim3(grid_for(upper)), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.view(),
+                           states_.data(), ctl_.data(), counters_.data(), g_);
         kernels += 1;
     }
 
@@ -1078,7 +1100,7 @@ public:
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
         WF_HIP_CHECK(hipMemsetAsync(&ctl_.data()->remaining, 0, sizeof(uint32_t), s));
         const unsigned rgrid = grid_for(hi - lo);
-        hipLaunchKernelGGL(wb_flush_plan_kernel, dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.data(), (uint32_t)lo, (uint32_t)hi, states_.data(),
+        hipLaunchKernelGGL((wb_flush_plan_kernel<key_t>), dim3(rgrid), dim3(BLOCK_THREADS), 0, s, table_.view(), (uint32_t)lo, (uint32_t)hi, states_.data(),
                            runs_.data(), n_fire_.data(), ctl_.data(), g_, quota);
         exclusive_scan_u32(n_fire_.data(), win_off_.data(), hi - lo, &ctl_.data()->win_total, scan_ws_.data(), s);
         evaluate(carry_.data(), out, s, 1);
@@ -1099,14 +1121,11 @@ public:
     }
 
 private:
-    struct KeyFn {
-        __host__ __device__ uint64_t operator()(const T& t) const { return (uint64_t)cf_key(t); }
-    };
     static constexpr unsigned EVAL_GRID = 1024;  // 4096 waves: 4 per SIMD on 256 CUs
 
     void evaluate(const T* base, Batch* out, hipStream_t s, uint32_t flushing) {
         // at most out_cap windows are described and evaluated; the grid-stride loops read the exact count on the device
-        hipLaunchKernelGGL((wb_desc_kernel<T, R>), dim3(grid_for(g_.out_cap)), dim3(BLOCK_THREADS), 0, s, table_.data(), states_.data(), runs_.data(),
+        hipLaunchKernelGGL((wb_desc_kernel<T, R>), dim3(grid_for(g_.out_cap)), dim3(BLOCK_THREADS), 0, s, table_.view(), states_.data(), runs_.data(),
                            win_off_.data(), n_fire_.data(), base, desc_.data(), out->template data<R>(), ctl_.data(), g_, flushing);
         if constexpr (is_map_reduce_t<F>::value) {
             hipLaunchKernelGGL((wb_eval_mapreduce_kernel<T, R, decltype(func_.map), decltype(func_.red)>), dim3(mr_grid_), dim3(BLOCK_THREADS), 0, s, base,
@@ -1116,8 +1135,12 @@ private:
             hipLaunchKernelGGL((wb_eval_reduce_kernel<T, R, decltype(func_.lift), decltype(func_.comb)>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base,
                                desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, func_.lift, func_.comb);
         } else if (tile_group_ > 0) {
+            // the workgroups loop over the groups of windows: no more of them than the chip holds at once (those without work
+            // leave at once, but each would still wait for its share of LDS)
+            const size_t tile_bytes = std::max<size_t>(16, (size_t)tile_tuples_ * sizeof(T));
+            const unsigned resident = tile_cus_ * (unsigned)std::max<size_t>(1, tile_lds_total_ / (tile_bytes + WB_TILE_STATIC_LDS));
             const unsigned groups = (unsigned)((g_.out_cap + tile_group_ - 1) / tile_group_);
-            hipLaunchKernelGGL((wb_eval_tile_kernel<T, R, F>), dim3(std::min(groups, WB_TILE_GRID)), dim3(WB_TILE_THREADS), (size_t)tile_tuples_ * sizeof(T),
+            hipLaunchKernelGGL((wb_eval_tile_kernel<T, R, F>), dim3(std::min(std::min(groups, WB_TILE_GRID), resident)), dim3(WB_TILE_THREADS), tile_bytes,
                                s, base, desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, tile_group_, tile_tuples_, tile_by_wave_,
                                scratch_.data(), scratch_size_, func_);
         } else {
@@ -1132,9 +1155,10 @@ private:
     WinGeometry g_{};
     size_t table_cap_ = 0, batch_cap_ = 0, n_tab_ = 0;
     int slot_bits_ = 0;
-    uint32_t tile_group_ = 0, tile_tuples_ = 0, tile_by_wave_ = 0;
+    uint32_t tile_group_ = 0, tile_tuples_ = 0, tile_by_wave_ = 0, tile_cus_ = 256;
+    size_t tile_lds_total_ = 64 * 1024;
     bool quiet_runs_ = true;  // short runs that fire no window are appended to the carry areas in place (wb_runs_kernel)
-    DeviceBuffer<unsigned long long> table_;
+    KeyTable<key_t> table_;
     DeviceBuffer<WinKeyState> states_;
     DeviceBuffer<T> carry_, work_;
     DeviceBuffer<uint32_t> slot_, idx_, work_len_, work_off_, n_fire_, win_off_, unsorted_stamp_;
