@@ -31,6 +31,9 @@ row "win_seq opaque keys=1024 16Ki" --pipeline win_seq --keys 1024 --batch 16384
 WF_SMALL_SORT=0 row "flagship host 16Ki WF_SMALL_SORT=0" --batch 16384
 GPU_MAX_HW_QUEUES=8 row "flagship host 16Ki GPU_MAX_HW_QUEUES=8" --batch 16384
 GPU_MAX_HW_QUEUES=8 row "flagship host 128Ki GPU_MAX_HW_QUEUES=8"
+GPU_MAX_HW_QUEUES=8 row "flagship device 128Ki GPU_MAX_HW_QUEUES=8" --source device
+GPU_MAX_HW_QUEUES=16 row "flagship device 128Ki GPU_MAX_HW_QUEUES=16" --source device
+GPU_MAX_HW_QUEUES=16 row "flagship device 16Ki GPU_MAX_HW_QUEUES=16" --source device --batch 16384
 cat $O/rows.txt
 for q in 4 16; do
 for a in "-o map_stateful -s 14 -n 14 -k 1000 -b 10000" "-o map_stateful -s 8 -n 8 -k 64 -b 131072" "-o filter_stateful -s 14 -n 14 -k 1000 -b 10000"; do

@@ -23,6 +23,8 @@ pytestmark = pytest.mark.gpu
     (3, 40_000, 64, 1024, 2, 4, 0),
     (2, 40_000, 500, 2048, 4, 2, 1),     # one batch per round
     (4, 30_000, 3, 512, 4, 2, 0),        # three keys per source: most (rank, lane) destinations stay empty, a few are hot
+    (8, 16_000, 1, 512, 2, 4, 0),        # eight ranks, one key per source: whole rounds land on a few lanes (more lane batches per
+                                         # round than the lane pool owns: they must be handed downstream as they fill)
 ])
 def test_exchange_conserves_and_routes(ext, world, n, keys, batch, sources, lanes, per_round):
     res = ext.exchange_local_run(0, world, n, keys, batch, sources, lanes, per_round)

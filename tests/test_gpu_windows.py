@@ -43,6 +43,34 @@ def test_radix_sort_pairs_is_stable_and_sorted(ext, n, bits):
     assert np.array_equal(sv, order)  # stability: equal keys keep arrival order
 
 
+@pytest.mark.parametrize("n,bits,mode", [(1, 8, 1), (2, 11, 1), (1000, 19, 1), (10_000, 12, 1), (16_384, 19, 1), (1, 8, 2), (1023, 8, 2), (1025, 9, 2),
+                                         (10_000, 19, 2), (131_072, 19, 2), (200_001, 24, 2), (50_000, 32, 2), (5000, 19, 3), (100_000, 19, 3)])
+def test_one_workgroup_sorts_behind_a_gate(ext, n, bits, mode):
+    """The sorts that run behind a SortGate: the bitonic network for small batches (mode 1), the one-workgroup radix sort of the
+    rescue path (mode 2) - both only execute when a batch that was expected to hold no key twice does - and the closed gate (3)."""
+    g = torch.Generator().manual_seed(bits * 11 + n + mode)
+    hi = (1 << bits) if bits < 31 else (1 << 31) - 1
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64)
+    if n > 100:
+        keys[::7] = keys[3]  # plenty of equal keys: stability matters
+    if bits >= 32:
+        keys = keys * 2 + torch.randint(0, 2, (n,), generator=g, dtype=torch.int64)
+    # values are NOT positions (the network sorts (key, position) words and gathers the values afterwards)
+    vals = torch.arange(n, dtype=torch.int64) * 3 + 5
+    dk = torch.from_numpy(keys.numpy().astype(np.uint32).view(np.int32)).cuda()
+    dv = torch.from_numpy(vals.numpy().astype(np.uint32).view(np.int32)).cuda()
+    ext.radix_sort_pairs(dk.data_ptr(), dv.data_ptr(), n, bits, mode)
+    torch.cuda.synchronize()
+    sk = dk.cpu().numpy().view(np.uint32).astype(np.int64)
+    sv = dv.cpu().numpy().view(np.uint32).astype(np.int64)
+    if mode == 3:
+        assert np.array_equal(sk, keys.numpy()) and np.array_equal(sv, vals.numpy())
+        return
+    order = np.argsort(keys.numpy(), kind="stable")
+    assert np.array_equal(sk, keys.numpy()[order])
+    assert np.array_equal(sv, vals.numpy()[order])
+
+
 def make_stream(n, n_keys, seed, ts_step=1, skew=False):
     rng = np.random.default_rng(seed)
     if skew:

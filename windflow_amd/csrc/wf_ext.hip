@@ -320,20 +320,30 @@ static py::tuple key_ffat_run(py::array_t<int64_t, py::array::c_style | py::arra
 }
 
 // stable radix sort of (key, value) pairs on the device (numerics test of the primitive)
-static void radix_sort_pairs(uintptr_t keys, uintptr_t vals, size_t n, int bits) {
+// mode 0: the multi-launch radix sort; 1: behind an OPEN gate (batches of at most 16 Ki pairs: the one-workgroup bitonic network);
+// 2: behind an open gate in rescue mode (the one-workgroup radix sort); 3: behind a CLOSED gate (nothing may move)
+static void radix_sort_pairs(uintptr_t keys, uintptr_t vals, size_t n, int bits, int mode) {
     check_ptr(keys, "keys");
     check_ptr(vals, "vals");
-    gpu::DeviceBuffer<uint32_t> n_dev(1);
-    const uint32_t n32 = (uint32_t)n;
-    WF_HIP_CHECK(hipMemcpy(n_dev.data(), &n32, 4, hipMemcpyHostToDevice));
+    gpu::DeviceBuffer<uint32_t> n_dev(2);
+    const uint32_t words[2] = {(uint32_t)n, 7u};
+    WF_HIP_CHECK(hipMemcpy(n_dev.data(), words, 8, hipMemcpyHostToDevice));
+    gpu::SortGate gate{};
+    if (mode != 0) gate = gpu::SortGate{n_dev.data() + 1, mode == 3 ? 8u : 7u, mode == 2 ? 1u : 0u};
     gpu::RadixSorter sorter;
-    auto sorted = sorter.sort(reinterpret_cast<uint32_t*>(keys), reinterpret_cast<uint32_t*>(vals), n_dev.data(), n, bits, 0);
+    gpu::Stream st;
+    hipStream_t s0 = st.get();
+    auto sorted = sorter.sort(reinterpret_cast<uint32_t*>(keys), reinterpret_cast<uint32_t*>(vals), n_dev.data(), n, bits, s0, gate);
+    if (mode == 3) {  // closed gate: the consumers read the unsorted arrays
+        WF_HIP_CHECK(hipStreamSynchronize(s0));
+        return;
+    }
     if (sorted.keys != reinterpret_cast<uint32_t*>(keys)) {
-        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(keys), sorted.keys, n * 4, hipMemcpyDeviceToDevice, 0));
-        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(vals), sorted.vals, n * 4, hipMemcpyDeviceToDevice, 0));
+        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(keys), sorted.keys, n * 4, hipMemcpyDeviceToDevice, s0));
+        WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<void*>(vals), sorted.vals, n * 4, hipMemcpyDeviceToDevice, s0));
     }
     WF_HIP_CHECK(hipGetLastError());
-    WF_HIP_CHECK(hipDeviceSynchronize());
+    WF_HIP_CHECK(hipStreamSynchronize(s0));
 }
 
 static uint32_t exclusive_scan(uintptr_t in, uintptr_t out, size_t n) {
@@ -1121,7 +1131,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("filter_compact", &filter_compact, py::arg("inp"), py::arg("n"), py::arg("out"), py::arg("mode"), py::arg("threshold"));
     m.def("key_ffat_run", &key_ffat_run, py::arg("tuples"), py::arg("win"), py::arg("slide"), py::arg("delay"), py::arg("time_based"),
           py::arg("max_keys"), py::arg("batch_len"), py::arg("out_capacity") = 0, py::arg("comb_mode") = 0, py::arg("skip_gaps") = false);
-    m.def("radix_sort_pairs", &radix_sort_pairs, py::arg("keys"), py::arg("vals"), py::arg("n"), py::arg("bits"));
+    m.def("radix_sort_pairs", &radix_sort_pairs, py::arg("keys"), py::arg("vals"), py::arg("n"), py::arg("bits"), py::arg("mode") = 0);
     m.def("exclusive_scan", &exclusive_scan, py::arg("inp"), py::arg("out"), py::arg("n"));
     py::class_<dist::Transport, std::shared_ptr<dist::Transport>>(m, "Transport")
         .def_property_readonly("rank", &dist::Transport::rank)

@@ -648,6 +648,19 @@ private:
         }
         tables_->clear();
         std::vector<std::pair<gpu::Batch*, size_t>> outs;
+        // One copy launch serves several lane batches, but never more than L of them are held back: a skewed round (every rank
+        // sends its whole round to one lane of this rank) needs more batches than the bounded pool owns, and slabs only come back
+        // once the batches acquired before them have been handed downstream.
+        auto hand_over = [&]() {
+            tables_->template launch<tuple_t>(s);
+            for (auto& ol : outs) {
+                ol.first->ready.record(s);
+                emit_to(ol.first, ol.second);
+            }
+            xstats_->lane_batches += outs.size();
+            outs.clear();
+            tables_->clear();
+        };
         for (size_t l = 0; l < L; l++) {
             size_t lane_total = 0;
             for (auto& pc : lane_src[l]) lane_total += pc.second;
@@ -682,14 +695,10 @@ private:
                 seq_ += n;
                 left -= n;
                 outs.push_back({out, l});
+                if (outs.size() >= L) hand_over();
             } while (left > 0);
         }
-        tables_->template launch<tuple_t>(s);
-        for (auto& ol : outs) {
-            ol.first->ready.record(s);
-            emit_to(ol.first, ol.second);
-        }
-        xstats_->lane_batches += outs.size();
+        if (!outs.empty()) hand_over();
     }
 
     // send buffers whose round the peers are done with go back to their pool

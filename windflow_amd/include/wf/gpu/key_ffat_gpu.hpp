@@ -281,10 +281,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 long_heads[atomicAdd(n_long, 1u)] = i;
             continue;
         }
-        FFATKeyState<R> st = states[slot];
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         R* acc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
         uint8_t* used = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
+        // (Requesting the tuple's open quantum and its flag together with the key's state - so that the dependent chain of the
+        // fold pays one trip to HBM instead of three - was tried and measured: 2.38-2.44 vs 2.46-2.51 G tuples/s, no gain.)
+        FFATKeyState<R> st = states[slot];
         GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
         // software prefetch: the tuples of a run are gathered FFAT_PREFETCH at a time so that
         // their (dependent, random) loads are in flight together
@@ -421,18 +423,6 @@ __device__ __forceinline__ void fat_rebuild_range_wave(R* tree, uint32_t cap, ui
     }
 }
 
-// What closes a batch: the result count is clamped to the capacity and mirrored for the host, the run counters are reset for the
-// next batch (same stream).  ffat_finalize_kernel does it in a launch of its own; the long-run kernel - always the last of a
-// batch - does it in its last workgroup to finish (a ticket) when it is handed one of these, which saves the launch.
-struct FFATFinish {
-    BatchHeader* out_hdr = nullptr;  // nullptr: the caller launches ffat_finalize_kernel
-    uint32_t cap = 0;
-    volatile uint32_t* mirror = nullptr;
-    uint32_t* n_long = nullptr;
-    uint32_t* n_huge = nullptr;
-    uint32_t* ticket = nullptr;
-};
-
 // Long runs: one wave64 per run, exploiting the associativity of the combine.
 //  * all chunks: the 64 lanes gather and LIFT the next 64 tuples of the run together; lanes whose tuples
 //    fall in the same pane (CB) / quantum (TB) form a segment and an order-preserving segmented wave scan
@@ -451,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
                             R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
                             const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb,
-                            volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0, FFATFinish fin = FFATFinish{}) {
+                            volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0) {
     extern __shared__ __align__(16) char ffat_smem[];
     const uint32_t n = hdr->count;
     const uint32_t runs = *n_long;
@@ -795,22 +785,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         if (lane == 0) states[slot] = st;
         wave_sync_lds();
     }
-    if (fin.out_hdr != nullptr) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(fin.ticket, 1u) == gridDim.x - 1) {  // every other workgroup is done
-                __threadfence();
-                uint32_t c = __hip_atomic_load(&fin.out_hdr->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c > fin.cap) c = fin.cap;
-                fin.out_hdr->count = c;
-                *fin.mirror = c;
-                *fin.n_long = 0;
-                if (fin.n_huge) *fin.n_huge = 0;
-                *fin.ticket = 0;
-            }
-        }
-    }
 }
 
 // end of stream: one thread per table slot; completes what is open and emits the
@@ -937,8 +911,8 @@ public:
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(FFATCounters), init.get()));
         long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
-        n_long_.resize(4);  // [0] long runs, [1] huge runs of the batch in flight, [2] ticket of the long-run kernel's workgroups
-        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 4 * sizeof(uint32_t), init.get()));
+        n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
+        WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
         // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones whose ring of open quanta is not enormous
         // (a long triggering delay keeps many quanta open: the scratch of a run spans all of them.  Sized for the 288 GB of an
         // MI355X: up to 2^18 open quanta per key as long as the scratch stays below 6 GB; beyond that the wave-per-run kernel)
@@ -1046,7 +1020,7 @@ private:
             const bool presort = g_.is_tb && !use_graphs_ && disorder_.decide(batch_no_);
             // a batch that holds no key twice skips the sort (decided on the device: primitives.hpp DupProbe)
             const DupProbe probe = (presort || use_graphs_) ? DupProbe{} : dups_.probe(batch_no_);
-            const SortGate gate = DupMonitor::gate(probe);
+            const SortGate gate = dups_.gate(probe);
             hipLaunchKernelGGL((assign_slots_kernel<T, key_t>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                table_.view(), slot_.data(), idx_.data(), &counters_.data()->table_full, out->header(), (uint32_t*)nullptr, probe);
             const auto sorted = presort ? presorter_.sort(in->header(), in->template data<T>(), in->device_count_ptr(), upper, slot_.data(), slot_bits_ + 1,
@@ -1095,22 +1069,21 @@ private:
             }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
-            // (its last workgroup also closes the batch: no finalize launch)
-            const FFATFinish fin{out->header(), g_.out_cap, out->count_mirror, n_long_.data(), n_long_.data() + 1, n_long_.data() + 2};
             if (long_layout_.bulk == 2)
                 hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_, fin);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
             else
                 hipLaunchKernelGGL((ffat_update_long_kernel<false, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
-                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_, fin);
-        } else {
-            hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
-                               n_long_.data() + 1);
+                                   long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
         }
+        // (Folding this into the last workgroup of the long-run kernel - a ticket - was tried and measured slower: device-fed
+        // flagship 2.31-2.49 G with the fold, 2.55-2.63 G with the launch; 16 Ki batches 720 vs 745 M tuples/s.)
+        hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror, n_long_.data(),
+                           n_long_.data() + 1);
     }
 
 public:

@@ -234,14 +234,25 @@ struct KeyTableView {
                     cur = prev;
                 }
                 if (cur == fp) {
-                    if (__hip_atomic_load(&ready[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) continue;
-                    if (keys[h] == key) return h;
+                    // the flag and the key are read with agent-scope atomic loads: coherent across the dies without an acquire
+                    // fence per probe (which would invalidate the caches of the whole compute unit for every tuple)
+                    if (__hip_atomic_load(&ready[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) continue;
+                    if (key_equals_coherent(&keys[h], key)) return h;
                 }
                 h = (h + 1) & mask;
                 probes++;
             }
             return 0xffffffffu;
         }
+    }
+    __device__ static __forceinline__ bool key_equals_coherent(const K* stored, const K& key) {
+        uint32_t mine[sizeof(K) / 4];
+        __builtin_memcpy(mine, &key, sizeof(K));
+        bool eq = true;
+#pragma unroll
+        for (size_t w = 0; w < sizeof(K) / 4; w++)
+            eq = eq && __hip_atomic_load(reinterpret_cast<const uint32_t*>(stored) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine[w];
+        return eq;
     }
     __device__ __forceinline__ bool occupied(uint32_t slot) const { return words[slot] != KEY_EMPTY; }
     __device__ __forceinline__ K key_at(uint32_t slot) const {
@@ -312,6 +323,7 @@ struct DupProbe {
 struct SortGate {
     const uint32_t* word = nullptr;  // nullptr: always run
     uint32_t value = 0;
+    uint32_t rescue = 0;  // 1: the gate is expected to stay closed - the whole sort is ONE launch (a single workgroup does it if it must)
     __device__ __forceinline__ bool closed() const { return word != nullptr && *word != value; }
 };
 // where the (slot, index) pairs of the batch are: sorted if the gate let the sort run, as assigned otherwise
@@ -392,18 +404,31 @@ public:
             last_seen_ = seen;
             off_until_ = batch_no + LINGER;
         }
-        if (batch_no < off_until_) return DupProbe{};
+        if (batch_no < off_until_) {
+            clean_from_ = 0;
+            return DupProbe{};
+        }
+        if (clean_from_ == 0) clean_from_ = batch_no;
         probed_++;
         return DupProbe{stamp_.data(), word_.data(), seen_, batch_no};
     }
-    static SortGate gate(const DupProbe& p) { return p.stamp ? SortGate{p.dup_batch, p.batch_no} : SortGate{}; }
+    // The gate of the sort launches behind a probed batch.  After CONFIDENT probed batches without a report (reports lag by the
+    // few batches in flight) the stream is taken to hold no repeats: the six gated launches of a sort shrink to one, whose single
+    // workgroup does the whole sort in the unlikely case that it is needed after all (slow, but only until the report of that
+    // batch has switched the probing off: a handful of batches at a change of regime).
+    SortGate gate(const DupProbe& p) const {
+        if (!p.stamp) return SortGate{};
+        const bool confident = rescue_ && clean_from_ != 0 && p.batch_no - clean_from_ >= CONFIDENT;
+        return SortGate{p.dup_batch, p.batch_no, confident ? 1u : 0u};
+    }
     uint64_t probed_batches() const { return probed_; }
 
 private:
-    static constexpr uint32_t LINGER = 64;
+    static constexpr uint32_t LINGER = 64, CONFIDENT = 32;
     volatile uint32_t* seen_ = nullptr;
     bool enabled_ = true;
-    uint32_t last_seen_ = 0, off_until_ = 0;
+    bool rescue_ = std::getenv("WF_SORT_RESCUE") == nullptr || std::atoi(std::getenv("WF_SORT_RESCUE")) != 0;
+    uint32_t last_seen_ = 0, off_until_ = 0, clean_from_ = 0;
     uint64_t probed_ = 0;
     DeviceBuffer<uint32_t> stamp_, word_;
 };
@@ -723,6 +748,94 @@ __global__ void __launch_bounds__(SMALL_SORT_THREADS)
     }
 }
 
+// ---- any batch: the whole radix sort in ONE launch (rescue path) ---------------------------------------------------------
+// Behind a gate that is expected to stay closed (SortGate::rescue) the sort is a single launch that returns at once.  If the
+// batch does hold a repeated key after all, its one workgroup runs every pass by itself: stable LSD, 8-bit digits, a histogram
+// over the batch, then rounds of 1024 pairs in input order - in-wave ranks from ballots, per-wave digit counts in LDS, running
+// offsets per digit carried from round to round.  Some hundred microseconds for 128 Ki pairs instead of tens - for the few
+// batches between a change of regime and the host noticing it (DupMonitor).
+constexpr int RESCUE_THREADS = 1024;
+constexpr int RESCUE_WAVES = RESCUE_THREADS / WAVE;
+__global__ void __launch_bounds__(RESCUE_THREADS)
+    rescue_sort_kernel(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr, uint32_t n_upper, int n_pass,
+                       SortGate gate) {
+    __shared__ uint32_t s_cnt[RESCUE_WAVES][RS_BINS];  // per-wave digit counts of a round, then their offsets
+    __shared__ uint32_t s_off[RS_BINS];                // where the next pair of every digit goes
+    __shared__ uint32_t s_wsum[RESCUE_WAVES];
+    if (gate.closed()) return;
+    uint32_t n = *n_ptr;
+    if (n > n_upper) n = n_upper;
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    for (int p = 0; p < n_pass; p++) {
+        const int shift = 8 * p;
+        // histogram of the pass
+        if (threadIdx.x < RS_BINS) s_off[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += RESCUE_THREADS) atomicAdd(&s_off[(kin[i] >> shift) & 0xff], 1u);
+        __syncthreads();
+        // exclusive scan of the 256 bins (threads 0..255 = waves 0..3)
+        uint32_t v = 0, inc = 0;
+        if (threadIdx.x < RS_BINS) {
+            v = s_off[threadIdx.x];
+            inc = wave_inclusive_scan(v);
+            if (lane == WAVE - 1) s_wsum[wave] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < RS_BINS) {
+            uint32_t off = inc - v;
+            for (int w = 0; w < wave; w++) off += s_wsum[w];
+            s_off[threadIdx.x] = off;
+        }
+        __syncthreads();
+        // rounds of 1024 pairs in input order
+        for (uint32_t base = 0; base < n; base += RESCUE_THREADS) {
+            for (int w = 0; w < RESCUE_WAVES; w += RESCUE_THREADS / RS_BINS) s_cnt[w + (int)(threadIdx.x / RS_BINS)][threadIdx.x % RS_BINS] = 0;
+            __syncthreads();
+            const uint32_t i = base + threadIdx.x;
+            const bool ok = i < n;
+            const uint32_t k = ok ? kin[i] : 0xffffffffu;
+            const uint32_t val = ok ? vin[i] : 0u;
+            const uint32_t digit = (k >> shift) & 0xff;
+            unsigned long long m = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bal = __ballot((digit >> b) & 1);
+                m &= ((digit >> b) & 1) ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+            if (ok && rank == 0) s_cnt[wave][digit] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x < RS_BINS) {
+                uint32_t run = s_off[threadIdx.x];
+                for (int w = 0; w < RESCUE_WAVES; w++) {
+                    const uint32_t c = s_cnt[w][threadIdx.x];
+                    s_cnt[w][threadIdx.x] = run;
+                    run += c;
+                }
+                s_off[threadIdx.x] = run;
+            }
+            __syncthreads();
+            if (ok) {
+                const uint32_t dst = s_cnt[wave][digit] + rank;
+                kout[dst] = k;
+                vout[dst] = val;
+            }
+            __syncthreads();
+        }
+        // the next pass reads what this one wrote: make the writes of all waves visible to all (one workgroup: a barrier and a
+        // workgroup-scope fence do)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+        uint32_t* t = kin;
+        kin = kout;
+        kout = t;
+        t = vin;
+        vin = vout;
+        vout = t;
+    }
+}
+
 // Workspace + driver for sorting up to `capacity` pairs.  `bits` = number of
 // significant key bits.  n is read from device memory so a data-dependent count
 // never has to come back to the host.
@@ -769,12 +882,21 @@ public:
         if (tiles == 0) return {kin, vin};
         uint32_t* kout = keys_tmp_.data();
         uint32_t* vout = vals_tmp_.data();
-        if (small_sort_ && n_upper <= (size_t)SMALL_SORT_MAX && n_upper <= small_lds_pairs_) {
+        // Only behind a gate that is expected to stay closed (the caller's DupProbe is on because recent batches held no key
+        // twice): one launch that returns at once instead of six.  A network of log^2 stages in one workgroup is slower than the
+        // multi-workgroup radix passes when it does have to run (measured: keyed map, 10 000-tuple batches full of repeats,
+        // 258 -> 126 M tuples/s), so streams whose batches repeat keys never take it.
+        if (small_sort_ && gate.word != nullptr && n_upper <= (size_t)SMALL_SORT_MAX && n_upper <= small_lds_pairs_) {
             uint32_t n_pow2 = 2;
             while (n_pow2 < n_upper) n_pow2 <<= 1;
             hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(SMALL_SORT_THREADS), (size_t)n_pow2 * sizeof(unsigned long long), s, kin, vin, kout, vout,
                                n_dev, n_pow2, gate);
             return {kout, vout};
+        }
+        if (gate.word != nullptr && gate.rescue != 0) {
+            const int n_pass8 = std::max(1, (bits + 7) / 8);
+            hipLaunchKernelGGL(rescue_sort_kernel, dim3(1), dim3(RESCUE_THREADS), 0, s, kin, vin, kout, vout, n_dev, (uint32_t)n_upper, n_pass8, gate);
+            return (n_pass8 & 1) ? Sorted{kout, vout} : Sorted{kin, vin};
         }
         const int d = digit_bits(bits), n_pass = passes(bits);
         // small batches (latency-oriented pipelines) are launch-bound: two launches per pass instead of three

@@ -1044,7 +1044,7 @@ public:
         const bool presort = g_.is_tb && !g_.renumber && disorder_.decide(batch_no_);
         // a batch that holds no key twice skips the sort (decided on the device: primitives.hpp DupProbe)
         const DupProbe probe = presort ? DupProbe{} : dups_.probe(batch_no_);
-        const SortGate gate = DupMonitor::gate(probe);
+        const SortGate gate = dups_.gate(probe);
         // also clears the header of the output batch and the run counter
         hipLaunchKernelGGL((assign_slots_kernel<T, key_t>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), table_.view(),
                            slot_.data(), idx_.data(), &counters_.data()->table_full, out->header(), &ctl_.data()->n_runs, probe);
