@@ -64,7 +64,7 @@ struct FFATHugeRun {
 
 template <typename T, typename R>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_huge_setup_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, const FFATKeyState<R>* states,
+    ffat_huge_setup_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATRecords<R> recs,
                            FFATGeometry g, const uint32_t* huge_heads, const uint32_t* n_huge, FFATHugeRun* runs, FFATHugeCtl* ctl, uint32_t max_runs,
                            uint32_t leaves_cap) {
     const uint64_t pane_len = g.pane_len;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         }
         hr.len = lo + 1 - hr.head;
         hr.n_chunks = (hr.len + WAVE - 1) / WAVE;
-        const FFATKeyState<R>& st = states[hr.slot];
+        const FFATKeyHeader st = recs.header(hr.slot);
         hr.P0 = st.panes;
         hr.first_lwid = st.next_lwid;
         if (!is_tb) {
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_huge_fix_kernel(FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used, FFATGeometry g, FFATHugeRun* runs,
+    ffat_huge_fix_kernel(FFATRecords<R> recs, R* trees, FFATGeometry g, FFATHugeRun* runs,
                          const FFATHugeCtl* ctl, const FFATPartial<R>* parts2, R* leaves, uint8_t* leaf_has, uint32_t* out_count, uint32_t* long_heads,
                          uint32_t* n_long, KeyTableView<K> table, FFATCounters* ctr, C comb, volatile uint32_t* disorder_seen = nullptr,
                          uint32_t batch_no = 0) {
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             }
             continue;
         }
-        FFATKeyState<R> st = states[hr.slot];
+        FFATKeyState<R> st = recs.load(hr.slot, g.is_tb);
         R* gtree = trees + (size_t)hr.slot * 2 * g.tree_cap;
         R* lv = leaves + (size_t)hr.leaf_base + (W - 1);  // lv[p] = pane P0 + p
         uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (W - 1);  // time-based: the pane received tuples (else it is a place holder)
@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         bool c_has = false;
         uint32_t c_pane = 0;
         R c_val{};
-        R* acc = g.is_tb ? accs + (size_t)hr.slot * g.acc_cap : nullptr;
-        uint8_t* used = g.is_tb ? acc_used + (size_t)hr.slot * g.acc_cap : nullptr;
+        R* acc = g.is_tb ? recs.ring(hr.slot) : nullptr;
+        uint8_t* used = g.is_tb ? recs.used(hr.slot) : nullptr;
         if (!g.is_tb && hr.pc0 > 0) {
             c_has = true;
             c_val = st.partial;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             if (k_end > st.next_lwid) st.next_lwid = k_end;
             hr.m = m;
             runs[r] = hr;
-            states[hr.slot] = st;
+            recs.store(hr.slot, st, g.is_tb);
             atomicAdd(&ctr->huge_runs, 1u);
         }
         m = (uint32_t)__shfl((int)m, 0, WAVE);

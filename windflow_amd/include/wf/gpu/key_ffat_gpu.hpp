@@ -48,15 +48,53 @@ struct FFATGeometry {
     uint32_t skip_gaps;   // TB: fast-forward over long stretches of empty windows instead of emitting them
 };
 
-template <typename R>
-struct FFATKeyState {
+struct FFATKeyHeader {
     uint64_t panes;         // completed panes inserted so far
     uint64_t next_lwid;     // next window to fire
     uint64_t last_quantum;  // TB: oldest open quantum
     uint64_t max_quantum;   // TB: greatest quantum that received a tuple (+1), 0 = none
     uint32_t pcount;        // CB: tuples in the open pane
     uint32_t seen;          // key has received at least one tuple
+};
+static_assert(sizeof(FFATKeyHeader) == 40, "FFATKeyHeader is 40 bytes");
+// the state of a key as the kernels hold it in registers
+template <typename R>
+struct FFATKeyState : FFATKeyHeader {
     R partial;              // CB: aggregate of the open pane
+};
+
+// Where the state of a key lives in HBM: ONE record per key,
+//     [ header 40 B | batch stamp 4 B (primitives.hpp DupProbe) | flags of the ring (acc_cap bytes) | pad to 8 | ring of acc_cap results ]
+// aligned to and padded to a multiple of 128 B (the line of the L2): the ring holds the open quanta of a time-based
+// window, or - slot 0 - the aggregate of the open pane of a count-based one.  With the usual two open quanta and 40-byte
+// results a record is exactly 128 B: a tuple that completes no pane reads one line and writes it back.  (Rounds 1 and 2
+// kept the state, the ring and its flags in three slabs: 4-5 lines per tuple, 312 B read + 289 B written per tuple measured.)
+// The tree of a key stays in a slab of its own: it is only touched when a pane completes.
+template <typename R>
+struct FFATRecords {
+    char* base = nullptr;
+    uint32_t stride = 0;    // bytes per key
+    uint32_t ring_off = 0;  // offset of the ring in a record
+    static constexpr uint32_t STAMP_OFF = sizeof(FFATKeyHeader);  // the probe for repeated keys stamps the record itself: the line
+                                                                 // is on its way into the caches when the update kernel asks for it
+    static constexpr uint32_t FLAGS_OFF = STAMP_OFF + 4;
+    static size_t ring_offset(uint32_t acc_cap) { return (FLAGS_OFF + (size_t)acc_cap + 7) & ~size_t(7); }
+    static size_t stride_for(uint32_t acc_cap) { return (ring_offset(acc_cap) + (size_t)acc_cap * sizeof(R) + 127) & ~size_t(127); }
+    __device__ __forceinline__ char* rec(uint32_t slot) const { return base + (size_t)slot * stride; }
+    __device__ __forceinline__ const FFATKeyHeader& header(uint32_t slot) const { return *reinterpret_cast<const FFATKeyHeader*>(rec(slot)); }
+    __device__ __forceinline__ R* ring(uint32_t slot) const { return reinterpret_cast<R*>(rec(slot) + ring_off); }
+    __device__ __forceinline__ uint8_t* used(uint32_t slot) const { return reinterpret_cast<uint8_t*>(rec(slot) + FLAGS_OFF); }
+    // count-based windows keep the open pane's aggregate in ring slot 0; time-based ones have no use for `partial`
+    __device__ __forceinline__ FFATKeyState<R> load(uint32_t slot, uint32_t is_tb) const {
+        FFATKeyState<R> st;
+        static_cast<FFATKeyHeader&>(st) = header(slot);
+        if (!is_tb) st.partial = ring(slot)[0];
+        return st;
+    }
+    __device__ __forceinline__ void store(uint32_t slot, const FFATKeyState<R>& st, uint32_t is_tb) const {
+        *reinterpret_cast<FFATKeyHeader*>(rec(slot)) = static_cast<const FFATKeyHeader&>(st);
+        if (!is_tb) ring(slot)[0] = st.partial;
+    }
 };
 
 struct FFATCounters {
@@ -255,8 +293,8 @@ __device__ __forceinline__ X wave_shfl_up(const X& v, int d) {
 // loads in one thread).
 template <typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_update_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, FFATKeyState<R>* states, R* trees,
-                       R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
+    ffat_update_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, FFATRecords<R> recs, R* trees,
+                       FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
                        uint32_t* n_long, L lift, C comb, uint32_t huge_mode = 0, uint32_t huge_len = 0, uint32_t* huge_heads = nullptr,
                        uint32_t* n_huge = nullptr, volatile uint32_t* huge_seen = nullptr, uint32_t batch_no = 0) {
     const uint32_t n = hdr->count;
@@ -282,11 +320,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             continue;
         }
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
-        R* acc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
-        uint8_t* used = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
-        // (Requesting the tuple's open quantum and its flag together with the key's state - so that the dependent chain of the
-        // fold pays one trip to HBM instead of three - was tried and measured: 2.38-2.44 vs 2.46-2.51 G tuples/s, no gain.)
-        FFATKeyState<R> st = states[slot];
+        R* acc = g.is_tb ? recs.ring(slot) : nullptr;
+        uint8_t* used = g.is_tb ? recs.used(slot) : nullptr;
+        FFATKeyState<R> st = recs.load(slot, g.is_tb);
         GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
         // software prefetch: the tuples of a run are gathered FFAT_PREFETCH at a time so that
         // their (dependent, random) loads are in flight together
@@ -309,7 +345,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 ffat_process_tuple(st, tree, acc, used, g, pre[u], lift, comb, emit, ctr);
             }
         }
-        states[slot] = st;
+        recs.store(slot, st, g.is_tb);
     }
 }
 
@@ -438,8 +474,8 @@ __device__ __forceinline__ void fat_rebuild_range_wave(R* tree, uint32_t cap, ui
 // The windows fired by a chunk leave with one atomic.
 template <bool GBULK, typename T, typename R, typename L, typename C>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATKeyState<R>* states, R* trees,
-                            R* accs, uint8_t* acc_used, FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
+    ffat_update_long_kernel(const BatchHeader* hdr, const T* data, const uint32_t* sslot, const uint32_t* sidx, FFATRecords<R> recs, R* trees,
+                            FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr,
                             const uint32_t* long_heads, const uint32_t* n_long, FFATLongLayout<R> lay, L lift, C comb,
                             volatile uint32_t* disorder_seen = nullptr, uint32_t batch_no = 0) {
     extern __shared__ __align__(16) char ffat_smem[];
@@ -462,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < runs; r += waves_total) {
         const uint32_t head = long_heads[r];
         const uint32_t slot = sslot[head];
-        FFATKeyState<R> st = states[slot];  // bulk: identical in every lane; otherwise lane 0's copy is the live one
+        FFATKeyState<R> st = recs.load(slot, g.is_tb);  // bulk: identical in every lane; otherwise lane 0's copy is the live one
         R* gtree = trees + (size_t)slot * 2 * g.tree_cap;
         // the tree of the bulk path (one instantiation per address space: ds_* or global_* instructions, not flat ones)
         R* wtree;
@@ -480,8 +516,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
         } else if (lay.tree_nodes != 0) {
             for (uint32_t k = lane; k < 2 * g.tree_cap; k += WAVE) ltree[k] = gtree[k];
         }
-        R* gacc = g.is_tb ? accs + (size_t)slot * g.acc_cap : nullptr;
-        uint8_t* gused = g.is_tb ? acc_used + (size_t)slot * g.acc_cap : nullptr;
+        R* gacc = g.is_tb ? recs.ring(slot) : nullptr;
+        uint8_t* gused = g.is_tb ? recs.used(slot) : nullptr;
         const bool acc_staged = g.is_tb && lay.acc_slots != 0;
         // the ring as the bulk path sees it (generic pointers: it touches a few slots per chunk)
         R* racc = acc_staged ? lacc : gacc;
@@ -782,7 +818,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 gused[k] = lused[k];
             }
         }
-        if (lane == 0) states[slot] = st;
+        if (lane == 0) recs.store(slot, st, g.is_tb);
         wave_sync_lds();
     }
 }
@@ -791,11 +827,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 // remaining (incomplete) windows, as the CPU engine does (win_seqffat.hpp flush)
 template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_flush_kernel(KeyTableView<K> table, uint32_t slot_lo, uint32_t slot_hi, FFATKeyState<R>* states, R* trees, R* accs, uint8_t* acc_used,
+    ffat_flush_kernel(KeyTableView<K> table, uint32_t slot_lo, uint32_t slot_hi, FFATRecords<R> recs, R* trees,
                       FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, C comb) {
     for (uint32_t slot = slot_lo + blockIdx.x * blockDim.x + threadIdx.x; slot < slot_hi; slot += gridDim.x * blockDim.x) {
         if (!table.occupied(slot)) continue;
-        FFATKeyState<R> st = states[slot];
+        FFATKeyState<R> st = recs.load(slot, g.is_tb);
         if (!st.seen) continue;
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
@@ -806,8 +842,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 st.pcount = 0;
             }
         } else {
-            R* acc = accs + (size_t)slot * g.acc_cap;
-            uint8_t* used = acc_used + (size_t)slot * g.acc_cap;
+            R* acc = recs.ring(slot);
+            uint8_t* used = recs.used(slot);
             while (st.last_quantum < st.max_quantum) {
                 const uint32_t a = (uint32_t)(st.last_quantum & (g.acc_cap - 1));
                 R pane{};
@@ -830,7 +866,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             st.next_lwid++;
             emit(res);
         }
-        states[slot] = st;
+        recs.store(slot, st, g.is_tb);
     }
 }
 
@@ -896,16 +932,11 @@ public:
         // never the legacy (null) stream: its implicit dependencies would break stream captures running in other threads
         Stream init;
         table_.init(table_cap_, init.get());
-        states_.resize(table_cap_);
-        WF_HIP_CHECK(hipMemsetAsync(states_.data(), 0, table_cap_ * sizeof(FFATKeyState<R>), init.get()));
+        rec_stride_ = FFATRecords<R>::stride_for(g_.acc_cap);
+        records_.resize(table_cap_ * rec_stride_);
+        WF_HIP_CHECK(hipMemsetAsync(records_.data(), 0, records_.bytes(), init.get()));
         trees_.resize((size_t)table_cap_ * 2 * g_.tree_cap);
         WF_HIP_CHECK(hipMemsetAsync(trees_.data(), 0, trees_.bytes(), init.get()));
-        if (g_.is_tb) {
-            accs_.resize((size_t)table_cap_ * g_.acc_cap);
-            WF_HIP_CHECK(hipMemsetAsync(accs_.data(), 0, accs_.bytes(), init.get()));
-            acc_used_.resize((size_t)table_cap_ * g_.acc_cap);
-            WF_HIP_CHECK(hipMemsetAsync(acc_used_.data(), 0, acc_used_.bytes(), init.get()));
-        }
         slot_.resize(batch_cap_);
         idx_.resize(batch_cap_);
         counters_.resize(1);
@@ -949,7 +980,7 @@ public:
         allow_dynamic_lds(&ffat_update_long_kernel<true, T, R, L, C>, long_lds_bytes_);
         allow_dynamic_lds(&ffat_update_long_kernel<false, T, R, L, C>, long_lds_bytes_);
         // the engine's kernels run on another stream: wait for the initialisation here
-        dups_.reserve(table_cap_, init.get());
+        dups_.use_external_stamps(reinterpret_cast<uint32_t*>(records_.data() + FFATRecords<R>::STAMP_OFF), (uint32_t)rec_stride_, init.get());
         init.sync();
         sorter_.reserve(batch_cap_);
         out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), out_capacity, pool_slabs));
@@ -963,7 +994,7 @@ public:
     KeyedFFATEngine& operator=(const KeyedFFATEngine&) = delete;
 
     const FFATGeometry& geometry() const { return g_; }
-    size_t device_bytes() const { return table_.bytes() + states_.bytes() + trees_.bytes() + accs_.bytes() + acc_used_.bytes(); }
+    size_t device_bytes() const { return table_.bytes() + records_.bytes() + trees_.bytes(); }
 
     // enqueue the processing of `in` on `s`; returns the batch of fired windows (count on device).
     // With WF_HIP_GRAPHS=1 the per-batch sequence (header clear, slot assignment, 3 kernels per sort
@@ -1036,12 +1067,12 @@ private:
                 huge_mode = (seen != 0 && batch_no_ - seen <= HUGE_LINGER_BATCHES) ? 2u : 1u;
             }
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
-                               sel, states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_,
+                               sel, recs(), trees_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), lift_,
                                comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_);
             if (huge_mode == 2) {
                 hipLaunchKernelGGL((ffat_huge_setup_kernel<T, R>), dim3(1), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys,
-                                   sorted.vals, states_.data(), g_, huge_heads_.data(), n_long_.data() + 1, huge_runs_.data(), huge_ctl_.data(),
+                                   sorted.vals, recs(), g_, huge_heads_.data(), n_long_.data() + 1, huge_runs_.data(), huge_ctl_.data(),
                                    huge_max_runs_, huge_leaves_cap_);
                 const unsigned cgrid = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (upper / WAVE + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
                 hipLaunchKernelGGL((ffat_huge_chunks_kernel<T, R, L, C>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, in->template data<T>(), sorted.vals,
@@ -1051,8 +1082,7 @@ private:
                 hipLaunchKernelGGL((ffat_huge_stitch_kernel<R, C>), dim3(sgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
                                    huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), huge_has_.data(), table_.view(), comb_);
                 const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
-                hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, states_.data(), trees_.data(), accs_.data(),
-                                   acc_used_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
+                hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, recs(), trees_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
                                    huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.view(), counters_.data(), comb_,
                                    disorder_.seen(), batch_no_);
                 const bool hgw = g_.win_panes > FFAT_HUGE_DIRECT_WIN;
@@ -1071,12 +1101,12 @@ private:
             const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
             if (long_layout_.bulk == 2)
                 hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
-                                   in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
+                                   in->template data<T>(), sorted.keys, sorted.vals, recs(), trees_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
                                    long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
             else
                 hipLaunchKernelGGL((ffat_update_long_kernel<false, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
-                                   in->template data<T>(), sorted.keys, sorted.vals, states_.data(), trees_.data(), accs_.data(), acc_used_.data(),
+                                   in->template data<T>(), sorted.keys, sorted.vals, recs(), trees_.data(),
                                    g_, out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(),
                                    long_layout_, lift_, comb_, disorder_.seen(), batch_no_);
         }
@@ -1103,7 +1133,7 @@ public:
         out->count_on_host = false;
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
         hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.view(), (uint32_t)lo, (uint32_t)hi,
-                           states_.data(), trees_.data(), accs_.data(), acc_used_.data(), g_, out->template data<R>(), out->device_count_ptr(),
+                           recs(), trees_.data(), g_, out->template data<R>(), out->device_count_ptr(),
                            counters_.data(), comb_);
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
         kernels += 2;
@@ -1125,10 +1155,10 @@ private:
     size_t table_cap_ = 0, batch_cap_ = 0;
     int slot_bits_ = 0;
     KeyTable<key_t> table_;
-    DeviceBuffer<FFATKeyState<R>> states_;
+    DeviceBuffer<char> records_;  // one record per table slot: header, ring flags, ring (FFATRecords)
+    size_t rec_stride_ = 0;
+    FFATRecords<R> recs() const { return FFATRecords<R>{records_.data(), (uint32_t)rec_stride_, (uint32_t)FFATRecords<R>::ring_offset(g_.acc_cap)}; }
     DeviceBuffer<R> trees_;
-    DeviceBuffer<R> accs_;
-    DeviceBuffer<uint8_t> acc_used_;
     DeviceBuffer<uint32_t> slot_, idx_;
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;

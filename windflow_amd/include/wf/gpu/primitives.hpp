@@ -315,7 +315,9 @@ private:
 // The sort kernels are launched with a SortGate and return at once unless the batch reported a repeat; consumers pick the
 // unsorted arrays in that case (SortedSel).
 struct DupProbe {
-    uint32_t* stamp = nullptr;               // [table slots]; nullptr: no probing (the batch is always sorted)
+    uint32_t* stamp = nullptr;               // stamp of slot 0; nullptr: no probing (the batch is always sorted)
+    uint32_t stamp_stride = 4;               // bytes from one slot's stamp to the next (4: an array of its own; more: the stamps live
+                                             // inside per-key records, so that the probe pulls in the line the update will need)
     uint32_t* dup_batch = nullptr;           // device word: number of the last batch in which a key occurred twice
     volatile uint32_t* dup_seen = nullptr;   // pinned copy of it for the host (DupMonitor)
     uint32_t batch_no = 0;
@@ -367,7 +369,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             // (the same slot twice under one LDS word = a repeat inside this block; a different slot just evicts)
             if (atomicExch(&s_seen[(s * 2654435761u) >> 22], s) == s)
                 dup = true;
-            else if (atomicMax(&probe.stamp[s], probe.batch_no) == probe.batch_no)
+            else if (atomicMax(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(probe.stamp) + (size_t)s * probe.stamp_stride), probe.batch_no) ==
+                     probe.batch_no)
                 dup = true;
         }
     }
@@ -392,13 +395,22 @@ public:
     DupMonitor& operator=(const DupMonitor&) = delete;
     void reserve(size_t table_slots, hipStream_t s) {
         stamp_.resize(table_slots);
+        stamp0_ = stamp_.data();
+        stride_ = 4;
         word_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(stamp_.data(), 0, stamp_.bytes(), s));
         WF_HIP_CHECK(hipMemsetAsync(word_.data(), 0, sizeof(uint32_t), s));
     }
+    // the stamps live in the caller's per-key records (zeroed by the caller): `first` = stamp of slot 0, `stride` bytes apart
+    void use_external_stamps(uint32_t* first, uint32_t stride, hipStream_t s) {
+        stamp0_ = first;
+        stride_ = stride;
+        word_.resize(1);
+        WF_HIP_CHECK(hipMemsetAsync(word_.data(), 0, sizeof(uint32_t), s));
+    }
     // called once per batch before its kernels are enqueued; batch numbers start at 1
     DupProbe probe(uint32_t batch_no) {
-        if (!enabled_ || stamp_.size() == 0) return DupProbe{};
+        if (!enabled_ || stamp0_ == nullptr) return DupProbe{};
         const uint32_t seen = *seen_;
         if (seen != last_seen_) {
             last_seen_ = seen;
@@ -410,7 +422,7 @@ public:
         }
         if (clean_from_ == 0) clean_from_ = batch_no;
         probed_++;
-        return DupProbe{stamp_.data(), word_.data(), seen_, batch_no};
+        return DupProbe{stamp0_, stride_, word_.data(), seen_, batch_no};
     }
     // The gate of the sort launches behind a probed batch.  After CONFIDENT probed batches without a report (reports lag by the
     // few batches in flight) the stream is taken to hold no repeats: the six gated launches of a sort shrink to one, whose single
@@ -430,6 +442,8 @@ private:
     bool rescue_ = std::getenv("WF_SORT_RESCUE") == nullptr || std::atoi(std::getenv("WF_SORT_RESCUE")) != 0;
     uint32_t last_seen_ = 0, off_until_ = 0, clean_from_ = 0;
     uint64_t probed_ = 0;
+    uint32_t* stamp0_ = nullptr;
+    uint32_t stride_ = 4;
     DeviceBuffer<uint32_t> stamp_, word_;
 };
 
