@@ -3,7 +3,7 @@
 // operators).  The reference publishes no numbers for them; this program gives ours, CPU and GPU
 // flavours side by side, on count-based sliding windows with a window sum.
 //
-//   bench_win_gpu -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide]
+//   bench_win_gpu -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|pf_gg|wmr_gg|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide]
 //                 [-b tuples per GPU batch] [-t seconds] [-B] [-D [-d delay]]
 // -D runs the tuple-fed graph in DEFAULT mode with TIME-based windows of the same geometry (a key ticks once per round of its
 // source; the sources are unsynchronised threads, so the windows get a triggering delay, -d, default 4 windows).
@@ -148,7 +148,7 @@ int main(int argc, char** argv) {
             case 'D': default_mode = true; break;
             case 'd': delay = std::strtoull(optarg, nullptr, 10); break;
             default:
-                std::cout << argv[0] << " -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide] "
+                std::cout << argv[0] << " -o kf|kf_gpu|wf_gpu|pf_gpu|wmr_gpu|pf_gg|wmr_gg|kff|kff_gpu [-s sources] [-n replicas] [-k keys] [-w win] [-l slide] "
                           << "[-b batch] [-t seconds]" << std::endl;
                 return 0;
         }
@@ -229,10 +229,16 @@ int main(int argc, char** argv) {
                    .withArchiveCapacity(archive).build_unique();
     } else if (op == "pf_gpu") {
         oper = windows(PaneFarmGPU_Builder(SumGPU(), sum2_nic)).withName(op).withParallelism(replicas, 1).withBatch(batch)
-                   .withMaxKeys(keys_per_source + 64).build_unique();
+                   .withMaxKeys(keys_per_source + 64).withArchiveCapacity(archive).build_unique();
     } else if (op == "wmr_gpu") {
         oper = windows(WinMapReduceGPU_Builder(SumGPU(), sum2_nic)).withName(op).withParallelism(std::max<size_t>(2, replicas), 1)
-                   .withBatch(batch).withMaxKeys(keys_per_source + 64).build_unique();
+                   .withBatch(batch).withMaxKeys(keys_per_source + 64).withArchiveCapacity(archive).build_unique();
+    } else if (op == "pf_gg") {  // both stages on the device: the producers fill batches, PLQ -> WLQ inside every replica
+        oper = windows(PaneFarmGPU_Builder(SumGPU(), Sum2GPU())).withName(op).withParallelism(replicas, replicas).withBatch(batch)
+                   .withMaxKeys(keys_per_source + 64).withArchiveCapacity(archive).build_unique();
+    } else if (op == "wmr_gg") {
+        oper = windows(WinMapReduceGPU_Builder(SumGPU(), Sum2GPU())).withName(op).withParallelism(4, replicas).withBatch(batch)
+                   .withMaxKeys(keys_per_source + 64).withArchiveCapacity(archive).build_unique();
     } else if (op == "kff") {
         oper = windows(KeyFFAT_Builder(lift_cpu, comb_cpu)).withName(op).withParallelism(replicas).build_unique();
     } else if (op == "kff_gpu") {

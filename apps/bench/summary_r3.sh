@@ -49,7 +49,7 @@ ops -o keyby -s 8 -n 4 -k 16384
 win() { echo "== bench_win_gpu $*" >&2; timeout -k 10 60 apps/bin/bench_win_gpu "$@" -t 3 2>&1 | tail -1 >> "$OUT/win.txt" || { echo "FAILED win $*" >&2; exit 1; }; }
 : > "$OUT/win.txt"
 # tuple-fed (CPU Source -> GPU window operator: the reference's programming model; the producers fill batches), DETERMINISTIC and DEFAULT
-for op in kf_gpu wf_gpu pf_gpu wmr_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536; done
+for op in kf_gpu wf_gpu pf_gpu wmr_gpu pf_gg wmr_gg kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536; done
 for op in kf_gpu wf_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536 -D; done
 # batch-fed
 for op in kf_gpu wf_gpu pf_gpu wmr_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 256 -b 131072 -B; done

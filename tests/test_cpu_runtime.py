@@ -41,6 +41,17 @@ def test_mp_windows_random_parallelism(op, mode):
     assert out.count("  OK") == 3 and "FAILED" not in out
 
 
+@pytest.mark.parametrize("op", ["wf", "kf", "kff", "pf", "wmr", "kf+pf"])
+def test_mp_windows_fixed_size_keys(op):
+    """The suite keyed by 16-byte fixed-size keys "key_<n>" (wf::FixedKey<16>, -DWF_TEST_FIXED_KEY): the CPU twin of the reference's
+    string-keyed programs (src/mp_test_cpu/mp_common_string.hpp); the same key type runs on the GPU operators (test_gpu_operators.py)."""
+    exe = wfbuild.build_cpp(os.path.join(HERE, "cpp", "test_mp_windows.cpp"), os.path.join(BIN, "test_mp_windows_fixedkey"),
+                            extra=["-DWF_TEST_FIXED_KEY"])
+    r = subprocess.run([exe, "-t", op, "-m", "cb", "-r", "2", "-l", "1200", "-k", "5", "-w", "14", "-s", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0 and r.stdout.count("  OK") == 2 and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("op", ["seq", "wf", "kf", "pf", "wmr"])
 @pytest.mark.parametrize("mode", ["cb", "tb"])
 def test_mp_windows_incremental_functions(op, mode):

@@ -323,9 +323,89 @@ public:
                 return new PaneFarmBatchGPU_Node<tuple_t, result_t, plq_t, wlq_t>(plq, wlq, p, o, cfg, kind, name, par, idx, closing, hub, counters);
             };
             flat_ = this->make_flat_stage(std::max(plq_parallelism, wlq_parallelism), name, default_routing);
+        } else if constexpr (gpu_plq) {
+            // The reference's own form - PLQ on the device, WLQ on the host (wf/pane_farm_gpu.hpp:124-337) - also gets a batch path:
+            // the panes are the tumbling windows of a KEYED device stage (replicas divide the keys instead of the panes: on a GPU the
+            // panes of a key are evaluated in parallel inside a replica), fed by the producers' batchers and the device KeyBy; its
+            // pane results - one per pane and key, numbered per key - come back as tuples for the WLQ replicas on the host.
+            const uint64_t pane = std::gcd(win_len, slide_len);
+            auto hub = this->hub_;
+            auto counters = this->bcounters_;
+            auto factory = [=](const WinParams& p0, const gpu::WinGPUOptions& o, edge_kind_t kind, size_t par, size_t idx) -> rt::Node* {
+                if (counters->size() < par) counters->resize(par);
+                WinParams p = p0;
+                p.role = PLQ;  // pane results are numbered per key: the ids the WLQ windows count
+                return new WinBatchGPU_Node<tuple_t, result_t, plq_t>(plq, p, o, cfg, kind, name + "_plq", par, idx, closing, hub, counters);
+            };
+            gpu::WinGPUOptions o1 = opt;
+            if (type == TB && o1.carry_capacity == 0) o1.carry_capacity = 1024;
+            hybrid_.reset(new GPU_Keyed_Window_Stage<tuple_t, result_t>(factory, pane, pane, triggering_delay, type, plq_parallelism, name + "_plq", cfg, o1,
+                                                                       default_routing));
+            hybrid_slabs_ = cfg.pool_slabs;
+            hybrid_wlq_par_ = wlq_parallelism;
+            hybrid_ordered_ = ordered;
         }
     }
-    WF_TWO_STAGE_GPU_BATCH_PATH(Pane_Farm<tuple_t WF_COMMA result_t>)
+    bool isGPUOperator() const override { return true; }
+    bool merges_batch_lanes_in_order() const override { return in_stage() && !in_stage()->key_disjoint(); }
+    bool takes_batch_lanes_one_to_one() const override { return in_stage() && in_stage()->key_disjoint(); }
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override {
+        return in_stage() && !this->prepared4nesting() ? in_stage()->batcher(m) : nullptr;
+    }
+    edge_kind_t output_kind() const override { return flat_ && flat_->kind != EDGE_TUPLE ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
+    bool accepts_input_kind(edge_kind_t k) const override { return in_stage() ? true : k == EDGE_TUPLE; }
+    void set_input_kind(edge_kind_t k) override {
+        if (in_stage()) in_stage()->kind = k;
+    }
+    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
+        return flat_ && flat_->kind != EDGE_TUPLE ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
+    }
+    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override {
+        if (flat_ && flat_->kind != EDGE_TUPLE) return flat_->build(g, this->hub_, m == Mode::DETERMINISTIC);
+        if (hybrid_ && hybrid_->kind != EDGE_TUPLE) return build_hybrid(g, m);
+        return Pane_Farm<tuple_t, result_t>::build_stages(g, m);
+    }
+    std::vector<gpu::WinCounters> getDeviceCounters() const { return *this->bcounters_; }
+
+private:
+    GPU_Keyed_Window_Stage<tuple_t, result_t>* in_stage() const { return flat_ ? flat_.get() : hybrid_.get(); }
+    // device PLQ stage (keyed, fed by batches) -> adapters -> host WLQ stage
+    std::vector<StageSpec> build_hybrid(rt::Graph& g, Mode m) {
+        std::vector<StageSpec> stages = hybrid_->build(g, this->hub_, m == Mode::DETERMINISTIC);
+        StageSpec& plq = stages.back();
+        auto adapters = batch_adapter_factory<result_t>(hybrid_slabs_);
+        for (rt::Node* r : plq.replicas) {
+            rt::Node* d2h = g.adopt(adapters(EDGE_DEVICE_BATCH));
+            rt::Node* unb = g.adopt(adapters(EDGE_HOST_BATCH));
+            g.connect_fused(r, r->add_out_port(), d2h);
+            g.connect_fused(d2h, d2h->add_out_port(), unb);
+            plq.outputs.push_back(unb);
+        }
+        auto grp = std::make_shared<TwoStageGroup>(this->make_wlq_group(g, this->getName()));
+        StageSpec wlq;
+        wlq.name = this->getName() + "_stage2";
+        wlq.routing = COMPLEX;
+        wlq.internal = true;
+        wlq.replicas = grp->second;
+        wlq.outputs = grp->second_outputs.empty() ? grp->second : grp->second_outputs;
+        wlq.make_emitter = [grp](rt::Graph& gr, size_t) { return grp->second_emitter(gr, 0); };
+        // no ordering node: the pane results of a key come from ONE device replica, in order (an ordering by id over the channels
+        // would wait for pane ids from replicas that never see the key)
+        stages.push_back(wlq);
+        if (hybrid_ordered_ && hybrid_wlq_par_ > 1) {
+            StageSpec c;
+            c.name = this->getName() + "_collector";
+            c.routing = FORWARD;
+            c.internal = true;
+            c.replicas.push_back(g.adopt(new Ordered_Collector<result_t>()));
+            c.make_emitter = [](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<result_t>(1), 1); };
+            stages.push_back(c);
+        }
+        return stages;
+    }
+    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_, hybrid_;
+    size_t hybrid_slabs_ = 6, hybrid_wlq_par_ = 1;
+    bool hybrid_ordered_ = true;
 };
 
 template <typename tuple_t, typename result_t>

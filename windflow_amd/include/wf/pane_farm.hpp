@@ -41,13 +41,13 @@ protected:
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t P = plq_par_, W = wlq_par_;
         const win_type_t type = type_;
-        group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix) {
+        group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix, bool with_plq) {
             TwoStageGroup grp;
             const uint64_t my_slide = slide * ctx.slide_mult;
             const uint64_t pane = std::gcd(win, my_slide);
             const uint64_t win_w = win / pane, slide_w = my_slide / pane;
             // ---- PLQ: tumbling windows of one pane ---------------------------
-            for (size_t i = 0; i < P; i++) {
+            for (size_t i = 0; with_plq && i < P; i++) {
                 WinParams p;
                 p.win_len = pane;
                 p.slide_len = pane * P;
@@ -101,11 +101,11 @@ public:
             fatal_error("Pane_Farm [" + name_ + "] has been prepared for nesting, it cannot be added directly to a MultiPipe");
         NestCtx ctx;
         ctx.slide_outer = slide_;
-        std::vector<TwoStageGroup> groups{group_factory_(g, ctx, name_)};
+        std::vector<TwoStageGroup> groups{group_factory_(g, ctx, name_, true)};
         return assemble_two_stage<tuple_t, result_t>(g, groups, type_, name_, nullptr, ordered_);
     }
     // ---- TwoStage_Operator ----------------------------------------------------
-    TwoStageGroup make_group(rt::Graph& g, const NestCtx& ctx, const std::string& prefix) override { return group_factory_(g, ctx, prefix); }
+    TwoStageGroup make_group(rt::Graph& g, const NestCtx& ctx, const std::string& prefix) override { return group_factory_(g, ctx, prefix, true); }
     uint64_t getWinLen() const override { return win_; }
     uint64_t getSlideLen() const override { return slide_; }
     uint64_t getTriggeringDelay() const override { return delay_; }
@@ -117,6 +117,16 @@ public:
     size_t getWLQParallelism() const { return wlq_par_; }
     void setPrepared4Nesting() { prepared4nesting_ = true; }
 
+protected:
+    // the WLQ stage alone (its replicas and the emitter that feeds them): for operators that compute the panes by other means
+    // (Pane_Farm_GPU fed by batches: one keyed device stage instead of the pane-parallel PLQ replicas)
+    TwoStageGroup make_wlq_group(rt::Graph& g, const std::string& prefix) {
+        NestCtx ctx;
+        ctx.slide_outer = slide_;
+        return group_factory_(g, ctx, prefix, false);
+    }
+    bool prepared4nesting() const { return prepared4nesting_; }
+
 private:
     std::string name_;
     uint64_t win_, slide_, delay_;
@@ -125,7 +135,7 @@ private:
     bool ordered_;
     opt_level_t opt_;
     bool prepared4nesting_ = false;
-    std::function<TwoStageGroup(rt::Graph&, const NestCtx&, const std::string&)> group_factory_;
+    std::function<TwoStageGroup(rt::Graph&, const NestCtx&, const std::string&, bool with_plq)> group_factory_;
 };
 
 }  // namespace wf
