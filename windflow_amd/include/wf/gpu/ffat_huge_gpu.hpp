@@ -12,7 +12,7 @@
 //   3. ffat_huge_stitch_kernel   one wave per 64 partials (two per chunk, in run order): the same segmented scan joins the
 //                                pieces of a pane that straddles chunks; panes that end inside the 64 are final (leaves),
 //                                the first and the last are again partials, of the next level (64 times fewer)
-//   4. ffat_huge_fix_kernel      one wave per run: stitches the second-level partials with what was open before the run,
+//   4. ffat_huge_fix_kernel      one workgroup per run: stitches the second-level partials with what was open before the run,
 //                                fills the panes no tuple fell into (time-based windows), appends the panes to the key's
 //                                tree in HBM, advances the key's state and reserves room in the output batch for the
 //                                windows the run fires
@@ -336,6 +336,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     }
 }
 
+// One workgroup per run.  The stitch of the second-level partials is a carry chain (wave 0, a handful of steps); everything
+// that is proportional to the number of panes - joining the run's panes with the key's ring of open quanta, handing the quanta
+// that stay open back to it, appending the complete panes to the key's tree - is done by all the waves of the group.
+// Time-based windows with a long triggering delay: the run's first pane sits far behind the oldest open quantum (the ring holds
+// many batches' worth of quanta).  Only the quanta the run completes (below Lq_new) and the ones it touches (from its first pane
+// on) pass through the leaves; what lies between stays in the ring untouched - the work is proportional to the run, not to the
+// ring (64 keys shared by 8 unsynchronised lanes, delay of 16 batches: 2.4 ms per run with one wave walking the ring, see
+// profiles/r3_shared_keys).
 template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_huge_fix_kernel(FFATRecords<R> recs, R* trees, FFATGeometry g, FFATHugeRun* runs,
@@ -343,41 +351,33 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                          uint32_t* n_long, KeyTableView<K> table, FFATCounters* ctr, C comb, volatile uint32_t* disorder_seen = nullptr,
                          uint32_t batch_no = 0) {
     const uint32_t nr = ctl->n_runs;
-    const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
     const int lane = lane_id();
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const bool w0 = wave_id() == 0;
     const uint32_t W = g.win_panes;
-    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < nr; r += waves_total) {
+    __shared__ uint32_t sh_cpane, sh_pfirst, sh_m;
+    for (uint32_t r = blockIdx.x; r < nr; r += gridDim.x) {
         FFATHugeRun hr = runs[r];
         if (hr.fallback) {
-            if (lane == 0) {
+            if (tid == 0) {
                 long_heads[atomicAdd(n_long, 1u)] = hr.head;
                 if ((hr.fallback & 2u) && disorder_seen != nullptr) *disorder_seen = batch_no;
             }
             continue;
         }
-        FFATKeyState<R> st = recs.load(hr.slot, g.is_tb);
         R* gtree = trees + (size_t)hr.slot * 2 * g.tree_cap;
         R* lv = leaves + (size_t)hr.leaf_base + (W - 1);  // lv[p] = pane P0 + p
         uint8_t* lh = leaf_has + (size_t)hr.leaf_base + (W - 1);  // time-based: the pane received tuples (else it is a place holder)
-        using key_t = decltype(cf_key(st.partial));
+        using key_t = decltype(cf_key(lv[0]));
         const key_t key = table.key_at(hr.slot);
         // the panes a window fired by this run can still need, in front of the new ones
-        for (uint32_t j = (uint32_t)lane; j + 1 < W; j += WAVE) {
+        for (uint32_t j = tid; j + 1 < W; j += nt) {
             const uint64_t back = (uint64_t)(W - 1 - j);  // pane P0 - back
             // (the key's first windows: the panes before pane 0 do not exist; no window reaches them, the block scans may)
             lv[-(int64_t)back] = hr.P0 >= back ? gtree[g.tree_cap + (uint32_t)((hr.P0 - back) & (g.tree_cap - 1))] : R{};
         }
-        // count-based: what was open before the run is the head of pane 0 (the carry is kept identical in every lane).
-        // time-based: the quanta that were open before the run (the key's ring) are joined with the run's panes afterwards
-        bool c_has = false;
-        uint32_t c_pane = 0;
-        R c_val{};
         R* acc = g.is_tb ? recs.ring(hr.slot) : nullptr;
         uint8_t* used = g.is_tb ? recs.used(hr.slot) : nullptr;
-        if (!g.is_tb && hr.pc0 > 0) {
-            c_has = true;
-            c_val = st.partial;
-        }
         auto put_leaf = [&](uint32_t p, const R& v) {
             R x = v;
             if (g.is_tb) {
@@ -392,66 +392,100 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             lv[p] = e;
             lh[p] = 0;
         };
-        // time-based: panes [from, to) received nothing (whole wave)
-        auto fill_gap = [&](uint32_t from, uint32_t to) {
-            for (uint32_t p = from + (uint32_t)lane; p < to; p += WAVE) put_empty(p);
-        };
-        const uint32_t n_entries = 2 * hr.n_units;
-        for (uint32_t e0 = 0; e0 < n_entries; e0 += WAVE) {
-            const uint32_t e = e0 + (uint32_t)lane;
-            const bool ok = e < n_entries;
-            FFATPartial<R> pe{};
-            if (ok) pe = parts2[2 * (size_t)hr.unit_base + e];
-            FFATStitched<R> sw = ffat_stitch_wave(ok, pe.pane, ok && pe.valid == 1, pe.val, comb);
-            // the carry joins the first segment, or is final
-            const uint32_t pane0 = (uint32_t)__shfl((int)pe.pane, 0, WAVE);
-            if (c_has && c_pane == pane0) {
-                if (sw.tail && sw.seg == 0) {
-                    R tmp;
-                    fat_combine(comb, c_val, sw.val, tmp);
-                    sw.val = tmp;
-                }
-            } else {
-                if (c_has && lane == 0) put_leaf(c_pane, c_val);
-                if (g.is_tb) fill_gap(c_has ? c_pane + 1 : 0, pane0);  // (lane 0 always holds the first partial of a unit)
+        const uint32_t m_tb = g.is_tb ? (uint32_t)(hr.Lq_new - hr.Lq) : 0u;  // time-based: quanta completed by the run
+        FFATKeyState<R> st{};
+        // the carry of the stitch (kept identical in every lane of wave 0).  Count-based: what was open before the run is the
+        // head of pane 0.  Time-based: the quanta that were open before the run (the key's ring) are joined afterwards.
+        bool c_has = false;
+        uint32_t c_pane = 0;
+        R c_val{};
+        if (w0) {
+            st = recs.load(hr.slot, g.is_tb);
+            if (!g.is_tb && hr.pc0 > 0) {
+                c_has = true;
+                c_val = st.partial;
             }
-            if (sw.tail && sw.seg < sw.n_segs - 1) put_leaf(pe.pane, sw.val);
-            if (g.is_tb && sw.boundary && lane > 0 && (e & 1u) == 0)
-                for (uint32_t p = sw.prev_pane + 1; p < pe.pane; p++) put_empty(p);
-            // the last segment is the new carry
-            const int last = (int)sw.cnt - 1;
-            c_val = wave_bcast(sw.val, last);
-            c_pane = (uint32_t)__shfl((int)pe.pane, last, WAVE);
-            c_has = true;
+            // time-based: panes [from, to) received nothing
+            auto fill_gap = [&](uint32_t from, uint32_t to) {
+                for (uint32_t p = from + (uint32_t)lane; p < to; p += WAVE) put_empty(p);
+            };
+            uint32_t p_first = 0;
+            const uint32_t n_entries = 2 * hr.n_units;
+            for (uint32_t e0 = 0; e0 < n_entries; e0 += WAVE) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                const bool ok = e < n_entries;
+                FFATPartial<R> pe{};
+                if (ok) pe = parts2[2 * (size_t)hr.unit_base + e];
+                FFATStitched<R> sw = ffat_stitch_wave(ok, pe.pane, ok && pe.valid == 1, pe.val, comb);
+                // the carry joins the first segment, or is final
+                const uint32_t pane0 = (uint32_t)__shfl((int)pe.pane, 0, WAVE);
+                if (c_has && c_pane == pane0) {
+                    if (sw.tail && sw.seg == 0) {
+                        R tmp;
+                        fat_combine(comb, c_val, sw.val, tmp);
+                        sw.val = tmp;
+                    }
+                } else {
+                    if (c_has && lane == 0) put_leaf(c_pane, c_val);
+                    if (g.is_tb) {  // (lane 0 always holds the first partial of a unit)
+                        if (c_has)
+                            fill_gap(c_pane + 1, pane0);
+                        else
+                            p_first = pane0;  // (the quanta in front of the run's first pane: filled by the whole group below)
+                    }
+                }
+                if (sw.tail && sw.seg < sw.n_segs - 1) put_leaf(pe.pane, sw.val);
+                if (g.is_tb && sw.boundary && lane > 0 && (e & 1u) == 0)
+                    for (uint32_t p = sw.prev_pane + 1; p < pe.pane; p++) put_empty(p);
+                // the last segment is the new carry
+                const int last = (int)sw.cnt - 1;
+                c_val = wave_bcast(sw.val, last);
+                c_pane = (uint32_t)__shfl((int)pe.pane, last, WAVE);
+                c_has = true;
+            }
+            if (lane == 0) {
+                if (g.is_tb) put_leaf(c_pane, c_val);
+                sh_cpane = c_pane;
+                sh_pfirst = p_first;
+            }
         }
-        wave_sync_lds();
+        __syncthreads();
         if (g.is_tb) {
             // The run's panes 0 .. c_pane are quanta Lq .. Lq + c_pane.  Join them with what the key's ring held for these quanta,
             // then the quanta below Lq_new are complete (leaves) and the others go (back) to the ring.
-            const uint32_t amask = g.acc_cap - 1, n_p = c_pane + 1, m_tb = (uint32_t)(hr.Lq_new - hr.Lq);
-            if (lane == 0) put_leaf(c_pane, c_val);
-            wave_sync_lds();
-            for (uint32_t p = (uint32_t)lane; p < n_p && p < g.acc_cap; p += WAVE) {
-                const uint32_t a = (uint32_t)((hr.Lq + p) & amask);
-                if (used[a]) {
-                    R x = acc[a];
-                    if (lh[p]) fat_combine(comb, acc[a], lv[p], x);
-                    put_leaf(p, x);
+            const uint32_t amask = g.acc_cap - 1, n_p = sh_cpane + 1, p_first = sh_pfirst;
+            for (uint32_t p = tid; p < p_first && p < m_tb; p += nt) put_empty(p);
+            __syncthreads();
+            auto join = [&](uint32_t from, uint32_t to) {
+                if (to > g.acc_cap) to = g.acc_cap;
+                for (uint32_t p = from + tid; p < to; p += nt) {
+                    const uint32_t a = (uint32_t)((hr.Lq + p) & amask);
+                    if (used[a]) {
+                        R x = acc[a];
+                        if (lh[p]) fat_combine(comb, acc[a], lv[p], x);
+                        put_leaf(p, x);
+                    }
                 }
+            };
+            if (p_first <= m_tb) {
+                join(0, n_p);
+            } else {
+                join(0, m_tb);
+                join(p_first, n_p);
             }
-            wave_sync_lds();
-            for (uint32_t p = (uint32_t)lane; p < m_tb && p < g.acc_cap; p += WAVE) used[(uint32_t)((hr.Lq + p) & amask)] = 0;
-            wave_sync_lds();
-            for (uint32_t p = m_tb + (uint32_t)lane; p < n_p; p += WAVE) {  // (at most acc_cap quanta: see the set-up kernel)
+            __syncthreads();
+            for (uint32_t p = tid; p < m_tb && p < g.acc_cap; p += nt) used[(uint32_t)((hr.Lq + p) & amask)] = 0;
+            __syncthreads();
+            // (at most acc_cap quanta: see the set-up kernel; the quanta between Lq_new and the run's first pane keep their ring entries)
+            for (uint32_t p = (p_first > m_tb ? p_first : m_tb) + tid; p < n_p; p += nt) {
                 const uint32_t a = (uint32_t)((hr.Lq + p) & amask);
                 if (lh[p]) acc[a] = lv[p];
                 used[a] = lh[p];
             }
-            wave_sync_lds();
         }
         // the last pane of the run: complete (count-based, when the run ends on a pane boundary) or left open
-        uint32_t m = 0;
-        if (lane == 0) {
+        if (tid == 0) {
+            uint32_t m = 0;
             if (!g.is_tb) {
                 const uint64_t total = (uint64_t)hr.pc0 + hr.len;
                 m = (uint32_t)(total / g.pane_len);
@@ -464,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     st.pcount = rem;
                 }
             } else {
-                m = (uint32_t)(hr.Lq_new - hr.Lq);  // the quanta from Lq_new on stay open
+                m = m_tb;  // the quanta from Lq_new on stay open
                 const uint64_t q1 = hr.Lq + c_pane;
                 st.last_quantum = hr.Lq_new;
                 if (q1 + 1 > st.max_quantum) st.max_quantum = q1 + 1;
@@ -480,17 +514,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             runs[r] = hr;
             recs.store(hr.slot, st, g.is_tb);
             atomicAdd(&ctr->huge_runs, 1u);
+            sh_m = m;
         }
-        m = (uint32_t)__shfl((int)m, 0, WAVE);
-        wave_sync_lds();
+        __syncthreads();
         // append the new panes to the key's tree (the newest tree_cap of them) and rebuild it
+        const uint32_t m = sh_m;
         const uint64_t Pn = hr.P0 + m;
         uint64_t lo = Pn > g.tree_cap ? Pn - g.tree_cap : 0;
         if (lo < hr.P0) lo = hr.P0;
-        for (uint64_t idx = lo + (uint64_t)lane; idx < Pn; idx += WAVE) gtree[g.tree_cap + (uint32_t)(idx & (g.tree_cap - 1))] = lv[idx - hr.P0];
-        wave_sync_lds();
-        if (m > 0) fat_rebuild_wave(gtree, g.tree_cap, comb);
-        wave_sync_lds();
+        for (uint64_t idx = lo + (uint64_t)tid; idx < Pn; idx += nt) gtree[g.tree_cap + (uint32_t)(idx & (g.tree_cap - 1))] = lv[idx - hr.P0];
+        __syncthreads();
+        if (w0 && m > 0) fat_rebuild_wave(gtree, g.tree_cap, comb);
+        __syncthreads();
     }
 }
 

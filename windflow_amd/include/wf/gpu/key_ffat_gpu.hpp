@@ -23,9 +23,11 @@
 //  * end-of-stream runs ffat_flush_kernel on the device (the reference falls back
 //    to the CPU: win_seqffat_gpu.hpp:543-660).
 #pragma once
+#include <algorithm>
 #include <map>
 #include <numeric>
 #include <tuple>
+#include <vector>
 
 #include "batch_ops.hpp"
 #include "flatfat_gpu.hpp"
@@ -660,7 +662,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     q_max = wave_bcast(qm, WAVE - 1);
                     simple = !disorder && late_mask == 0;  // the segments of the scan above are the chunk's quanta
                 }
-                fast = Lq_new - Lq <= (uint64_t)WAVE;    // (a jump in time: the sequential rules know how to skip the empty stretch)
+                // (the quanta the chunk completes are taken 64 at a time, see below; a jump in time beyond what the ring of open
+                // quanta can hold is an empty stretch: the sequential rules know how to skip it)
+                fast = Lq_new - Lq <= (uint64_t)(g.acc_cap > (uint32_t)WAVE ? g.acc_cap : (uint32_t)WAVE);
             }
             if (fast) {
                 const auto key = wave_bcast(cf_key(val), 0);
@@ -679,11 +683,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     const R last_val = wave_bcast(open_val, (int)cnt - 1);  // the last segment: the new open pane when rem > 0
                     st.pcount = rem;
                     if (rem > 0) st.partial = last_val;
+                    st.panes = P + m;
+                    pend += m;
                 } else {
                     const uint64_t Lq = st.last_quantum;
-                    m = (uint32_t)(Lq_new - Lq);
-                    if (pend + m > (uint32_t)WAVE) fire_pending();
                     const uint32_t amask = g.acc_cap - 1;
+                    run_key = key;  // (fire_pending stamps the windows with it)
                     // one lane per quantum the chunk touches holds the fold of the chunk's tuples of that quantum, in arrival order
                     bool qtail = tail;
                     R qval = val;
@@ -720,27 +725,39 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                             rem &= ~members;
                         }
                     }
-                    // every completed quantum starts from what the ring of open quanta holds for it (or as an empty pane) ...
-                    if ((uint32_t)lane < m) {
-                        const uint64_t qq = Lq + (uint64_t)lane;
-                        R e{};
-                        if ((uint32_t)lane < g.acc_cap && rused[(uint32_t)(qq & amask)]) e = racc[(uint32_t)(qq & amask)];
-                        e.setControlFields(key, qq, (qq + 1) * g.pane_len - 1);
-                        wtree[CW + (uint32_t)((P + (uint64_t)lane) & (CW - 1))] = e;
+                    // The quanta below Lq_new are complete, 64 of them at a time (a chunk usually completes a handful; a chunk that
+                    // follows a jump in time - the piece of a lane that runs ahead of the others - completes what the triggering
+                    // delay had kept open, thousands of quanta: lane 0 used to walk them one by one, milliseconds per run).
+                    for (uint64_t b = Lq; b < Lq_new;) {
+                        const uint32_t ms = (uint32_t)(Lq_new - b < (uint64_t)WAVE ? Lq_new - b : (uint64_t)WAVE);
+                        if (pend + ms > (uint32_t)WAVE) fire_pending();
+                        const uint64_t Pb = st.panes;
+                        const uint64_t off = b - Lq;  // (the ring holds the acc_cap quanta from Lq on)
+                        // every completed quantum starts from what the ring of open quanta holds for it (or as an empty pane) ...
+                        if ((uint32_t)lane < ms) {
+                            const uint64_t qq = b + (uint64_t)lane;
+                            R e{};
+                            if (off + (uint64_t)lane < (uint64_t)g.acc_cap && rused[(uint32_t)(qq & amask)]) e = racc[(uint32_t)(qq & amask)];
+                            e.setControlFields(key, qq, (qq + 1) * g.pane_len - 1);
+                            wtree[CW + (uint32_t)((Pb + (uint64_t)lane) & (CW - 1))] = e;
+                        }
+                        wave_sync_lds();
+                        // ... the chunk's tuples of a completed quantum join it ...
+                        if (qtail && segkey >= b && segkey < b + ms) {
+                            const uint32_t x = (uint32_t)(segkey - b), a = (uint32_t)(segkey & amask);
+                            R v = qval;
+                            if (segkey - Lq < (uint64_t)g.acc_cap && rused[a]) fat_combine(comb, racc[a], qval, v);
+                            v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
+                            wtree[CW + (uint32_t)((Pb + (uint64_t)x) & (CW - 1))] = v;
+                        }
+                        wave_sync_lds();
+                        // ... their slots in the ring are free again ...
+                        if ((uint32_t)lane < ms && off + (uint64_t)lane < (uint64_t)g.acc_cap) rused[(uint32_t)((b + (uint64_t)lane) & amask)] = 0;
+                        wave_sync_lds();
+                        st.panes = Pb + ms;
+                        pend += ms;
+                        b += ms;
                     }
-                    wave_sync_lds();
-                    // ... the chunk's tuples of a completed quantum join it ...
-                    if (qtail && segkey < Lq_new) {
-                        const uint32_t x = (uint32_t)(segkey - Lq), a = (uint32_t)(segkey & amask);
-                        R v = qval;
-                        if (x < g.acc_cap && rused[a]) fat_combine(comb, racc[a], qval, v);
-                        v.setControlFields(key, segkey, (segkey + 1) * g.pane_len - 1);
-                        wtree[CW + (uint32_t)((P + (uint64_t)x) & (CW - 1))] = v;
-                    }
-                    wave_sync_lds();
-                    // ... their slots in the ring are free again ...
-                    if ((uint32_t)lane < m && (uint32_t)lane < g.acc_cap) rused[(uint32_t)((Lq + (uint64_t)lane) & amask)] = 0;
-                    wave_sync_lds();
                     // ... and the tuples of the quanta that stay open are folded into the ring
                     if (qtail && segkey >= Lq_new) {
                         const uint32_t a = (uint32_t)(segkey & amask);
@@ -758,8 +775,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                     if (n_late < cnt && q_max + 1 > st.max_quantum) st.max_quantum = q_max + 1;
                 }
                 st.seen = 1;
-                st.panes = P + m;
-                pend += m;
                 run_key = key;
                 wave_sync_lds();
             } else {
@@ -825,14 +840,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 
 // end of stream: one thread per table slot; completes what is open and emits the
 // remaining (incomplete) windows, as the CPU engine does (win_seqffat.hpp flush)
+// (the slots that hold a key that received tuples, compacted first: a round of the flush then never walks over empty slots -
+// with a long triggering delay a round holds three or four keys, and the table of a replica may be mostly empty)
+template <typename R, typename K>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+    ffat_flush_list_kernel(KeyTableView<K> table, FFATRecords<R> recs, uint32_t table_cap, uint32_t* list, uint32_t* count) {
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < table_cap; slot += gridDim.x * blockDim.x)
+        if (table.occupied(slot) && recs.header(slot).seen) list[atomicAdd(count, 1u)] = slot;
+}
+
 template <typename R, typename C, typename K>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    ffat_flush_kernel(KeyTableView<K> table, uint32_t slot_lo, uint32_t slot_hi, FFATRecords<R> recs, R* trees,
+    ffat_flush_kernel(KeyTableView<K> table, const uint32_t* list, uint32_t lo, uint32_t hi, FFATRecords<R> recs, R* trees,
                       FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, C comb) {
-    for (uint32_t slot = slot_lo + blockIdx.x * blockDim.x + threadIdx.x; slot < slot_hi; slot += gridDim.x * blockDim.x) {
-        if (!table.occupied(slot)) continue;
+    for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = list[i];
         FFATKeyState<R> st = recs.load(slot, g.is_tb);
-        if (!st.seen) continue;
         R* tree = trees + (size_t)slot * 2 * g.tree_cap;
         GlobalEmit<R> emit{out, out_count, g.out_cap, ctr};
         const auto key = table.key_at(slot);
@@ -1081,7 +1104,7 @@ private:
                 const unsigned sgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (upper / WAVE / 32 + huge_max_runs_) / (BLOCK_THREADS / WAVE) + 1));
                 hipLaunchKernelGGL((ffat_huge_stitch_kernel<R, C>), dim3(sgrid), dim3(BLOCK_THREADS), 0, s, g_, huge_runs_.data(), huge_ctl_.data(),
                                    huge_parts_.data(), huge_parts2_.data(), huge_leaves_.data(), huge_has_.data(), table_.view(), comb_);
-                const unsigned fgrid = (unsigned)std::max<size_t>(1, (huge_max_runs_ + BLOCK_THREADS / WAVE - 1) / (BLOCK_THREADS / WAVE));
+                const unsigned fgrid = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, huge_max_runs_));  // a workgroup per run
                 hipLaunchKernelGGL((ffat_huge_fix_kernel<R, C>), dim3(fgrid), dim3(BLOCK_THREADS), 0, s, recs(), trees_.data(), g_, huge_runs_.data(), huge_ctl_.data(), huge_parts2_.data(), huge_leaves_.data(),
                                    huge_has_.data(), out->device_count_ptr(), long_heads_.data(), n_long_.data(), table_.view(), counters_.data(), comb_,
                                    disorder_.seen(), batch_no_);
@@ -1123,17 +1146,38 @@ public:
     // the bounded output pool never deadlocks.
     // flush one slot range at a time (bounded number of output batches in flight)
     bool flush_range(size_t& cursor, hipStream_t s, uint64_t& kernels, Batch*& out) {
-        if (cursor >= table_cap_) return false;
+        if (cursor == 0) {
+            // the keys to flush, in slot order (the order of the results of different keys then does not depend on the atomics)
+            flush_list_.resize(table_cap_ + 1);
+            uint32_t* count = flush_list_.data() + table_cap_;
+            WF_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL((ffat_flush_list_kernel<R>), dim3(grid_for(table_cap_)), dim3(BLOCK_THREADS), 0, s, table_.view(), recs(),
+                               (uint32_t)table_cap_, flush_list_.data(), count);
+            kernels++;
+            uint32_t n = 0;
+            WF_HIP_CHECK(hipMemcpyAsync(&n, count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            WF_HIP_CHECK(hipStreamSynchronize(s));
+            flush_n_ = n;
+            if (n > 1) {
+                std::vector<uint32_t> h(n);
+                WF_HIP_CHECK(hipMemcpyAsync(h.data(), flush_list_.data(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                WF_HIP_CHECK(hipStreamSynchronize(s));
+                std::sort(h.begin(), h.end());
+                WF_HIP_CHECK(hipMemcpyAsync(flush_list_.data(), h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                WF_HIP_CHECK(hipStreamSynchronize(s));
+            }
+        }
+        if (cursor >= flush_n_) return false;
         const size_t per_key = (size_t)g_.win_panes / g_.slide_panes + 2 + (g_.is_tb ? g_.acc_cap : 0);
         const size_t slots_per_round = std::max<size_t>(1, g_.out_cap / per_key);
-        const size_t lo = cursor, hi = std::min(table_cap_, lo + slots_per_round);
+        const size_t lo = cursor, hi = std::min(flush_n_, lo + slots_per_round);
         cursor = hi;
         out = out_pool_->acquire(s);
         out->host_hdr = BatchHeader{};
         out->count_on_host = false;
         WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
-        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.view(), (uint32_t)lo, (uint32_t)hi,
-                           recs(), trees_.data(), g_, out->template data<R>(), out->device_count_ptr(),
+        hipLaunchKernelGGL((ffat_flush_kernel<R, C>), dim3(grid_for(hi - lo)), dim3(BLOCK_THREADS), 0, s, table_.view(), flush_list_.data(), (uint32_t)lo,
+                           (uint32_t)hi, recs(), trees_.data(), g_, out->template data<R>(), out->device_count_ptr(),
                            counters_.data(), comb_);
         hipLaunchKernelGGL(ffat_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), g_.out_cap, out->count_mirror);
         kernels += 2;
@@ -1160,6 +1204,8 @@ private:
     FFATRecords<R> recs() const { return FFATRecords<R>{records_.data(), (uint32_t)rec_stride_, (uint32_t)FFATRecords<R>::ring_offset(g_.acc_cap)}; }
     DeviceBuffer<R> trees_;
     DeviceBuffer<uint32_t> slot_, idx_;
+    DeviceBuffer<uint32_t> flush_list_;  // end of stream: the slots to flush, then their number
+    size_t flush_n_ = 0;
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;
     FFATLongLayout<R> long_layout_{0, 0, 0};
