@@ -87,6 +87,18 @@ template <typename F, typename = void>
 struct is_map_reduce_t : std::false_type {};
 template <typename F>
 struct is_map_reduce_t<F, std::void_t<decltype(F::is_map_reduce)>> : std::true_type {};
+// map_only(map, M): the MAP stage alone - the engine emits the M partial results of every window (ids M * k + m for the k-th
+// window of a key, as the M MAP replicas of the host operator number them: wf/win_mapreduce.hpp), the REDUCE stage runs
+// elsewhere (Win_MapReduce_GPU with a host REDUCE function)
+struct NoReduce {};
+template <typename MapF>
+inline MapReduceFunc<MapF, NoReduce> map_only(MapF map, size_t stripes) {
+    return MapReduceFunc<MapF, NoReduce>{map, NoReduce{}, (uint32_t)(stripes < 1 ? 1 : stripes)};
+}
+template <typename F>
+struct is_map_only_t : std::false_type {};
+template <typename MapF>
+struct is_map_only_t<MapReduceFunc<MapF, NoReduce>> : std::true_type {};
 
 // ---- parameters -----------------------------------------------------------------------------
 struct WinGeometry {
@@ -715,8 +727,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 // legal one).  `partials`: per-workgroup array of `stripes` results.
 template <typename T, typename R, typename MapF, typename RedF>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-    wb_eval_mapreduce_kernel(const T* base, const WinDesc* desc, R* out, const WinCtl* ctl, uint32_t out_cap, T* area, uint32_t area_tuples, R* partials,
-                             uint32_t stripes, char* scratch, size_t scratch_size, MapF map, RedF red) {
+    wb_eval_mapreduce_kernel(const T* base, const WinDesc* desc, const R* stamps, R* out, const WinCtl* ctl, uint32_t out_cap, T* area, uint32_t area_tuples,
+                             R* partials, uint32_t stripes, char* scratch, size_t scratch_size, MapF map, RedF red) {
     uint32_t n_win = ctl->win_total;
     if (n_win > out_cap) n_win = out_cap;
     T* my_area = area + (size_t)blockIdx.x * area_tuples;
@@ -735,7 +747,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
                 my_area[(size_t)m * q + (m < rem ? m : rem) + p / M] = src[p];
             }
         __syncthreads();
-        const R stamped = out[w];
+        const R stamped = stamps[w];  // (map + reduce: the pre-stamped result itself, stamps == out)
+        if constexpr (std::is_same_v<RedF, NoReduce>) {
+            // MAP stage alone: `stripes` partial results per window, whatever the partition (a stripe may be empty)
+            if (threadIdx.x < stripes) {
+                const uint32_t m = threadIdx.x;
+                const uint64_t id = cf_id(stamped) + m;  // (role MAP: the window's stamp carries stripes * k)
+                R part{};
+                part.setControlFields(cf_key(stamped), id, cf_ts(stamped));
+                const T* stripe = M > 1 ? my_area + (size_t)m * q + (m < rem ? m : rem) : src;
+                const size_t cnt = m < M ? (size_t)(q + (m < rem ? 1u : 0u)) : 0;
+                map(d.gwid, stripe, cnt, &part, my_scratch, scratch_size);
+                part.setControlFields(cf_key(stamped), id, cf_ts(stamped));
+                out[(size_t)w * stripes + m] = part;
+            }
+            __syncthreads();
+            continue;
+        }
         if (threadIdx.x < M) {
             const uint32_t m = threadIdx.x;
             R part{};
@@ -746,11 +774,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             my_part[m] = part;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            R res = stamped;
-            red(d.gwid, static_cast<const R*>(my_part), (size_t)M, &res, my_scratch, scratch_size);
-            res.setControlFields(cf_key(stamped), cf_id(stamped), cf_ts(stamped));
-            out[w] = res;
+        if constexpr (!std::is_same_v<RedF, NoReduce>) {
+            if (threadIdx.x == 0) {
+                R res = stamped;
+                red(d.gwid, static_cast<const R*>(my_part), (size_t)M, &res, my_scratch, scratch_size);
+                res.setControlFields(cf_key(stamped), cf_id(stamped), cf_ts(stamped));
+                out[w] = res;
+            }
         }
         __syncthreads();
     }
@@ -852,13 +882,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
 }
 
 // clamp the result count to the capacity (the windows beyond it were deferred, see wb_commit_kernel) and mirror it for the host
-__global__ void wb_finalize_kernel(BatchHeader* out_hdr, const WinCtl* ctl, uint32_t cap, volatile uint32_t* mirror, WinCounters* ctr) {
+// (`per_window`: results per fired window - the MAP stage alone emits one per stripe)
+__global__ void wb_finalize_kernel(BatchHeader* out_hdr, const WinCtl* ctl, uint32_t cap, volatile uint32_t* mirror, WinCounters* ctr,
+                                   uint32_t per_window = 1) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t c = ctl->win_total;
         if (c > cap) {
             atomicAdd(&ctr->deferred, c - cap);
             c = cap;
         }
+        c *= per_window;
         out_hdr->count = c;
         *mirror = c;
     }
@@ -1011,7 +1044,12 @@ public:
         dups_.reserve(table_cap_, init.get());
         init.sync();
         sorter_.reserve(batch_cap_);
-        out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), g_.out_cap, pool_slabs));
+        if constexpr (is_map_only_t<F>::value) {
+            per_window_ = func_.stripes;
+            if ((uint64_t)g_.out_cap * per_window_ >= (1ull << 31)) failwith("Win_MapReduce_GPU: output capacity x map parallelism too large for one batch");
+            stamps_.resize(g_.out_cap);
+        }
+        out_pool_.reset(new BatchPool(MemKind::DEVICE, device_, sizeof(R), (size_t)g_.out_cap * per_window_, pool_slabs));
     }
     WinBatchEngine(const WinBatchEngine&) = delete;
     WinBatchEngine& operator=(const WinBatchEngine&) = delete;
@@ -1030,7 +1068,7 @@ public:
         if (upper == 0) {
             WF_HIP_CHECK(hipMemsetAsync(out->header(), 0, sizeof(BatchHeader), s));
             WF_HIP_CHECK(hipMemsetAsync(&ctl_.data()->win_total, 0, sizeof(uint32_t), s));
-            hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data());
+            hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data(), per_window_);
             kernels += 1;
             return out;
         }
@@ -1072,7 +1110,7 @@ public:
             hipLaunchKernelGGL((wb_commit_kernel<T>), dim3(cgrid), dim3(BLOCK_THREADS), 0, s, table_.view(), states_.data(), runs_.data(), n_fire_.data(),
                                win_off_.data(), work_.data(), carry_.data(), ctl_.data(), counters_.data(), g_, chunks);
         }
-        hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data());
+        hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data(), per_window_);
         kernels += 10 + sorter_.kernels_per_sort(slot_bits_ + 1);
         return out;
     }
@@ -1104,7 +1142,7 @@ public:
                            runs_.data(), n_fire_.data(), ctl_.data(), g_, quota);
         exclusive_scan_u32(n_fire_.data(), win_off_.data(), hi - lo, &ctl_.data()->win_total, scan_ws_.data(), s);
         evaluate(carry_.data(), out, s, 1);
-        hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data());
+        hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, s, out->header(), ctl_.data(), g_.out_cap, out->count_mirror, counters_.data(), per_window_);
         kernels += 6;
         WinCtl c{};
         WF_HIP_CHECK(hipMemcpyAsync(&c, ctl_.data(), sizeof(c), hipMemcpyDeviceToHost, s));
@@ -1125,12 +1163,14 @@ private:
 
     void evaluate(const T* base, Batch* out, hipStream_t s, uint32_t flushing) {
         // at most out_cap windows are described and evaluated; the grid-stride loops read the exact count on the device
+        // (the MAP stage alone writes several results per window: the windows' stamps then live in an array of their own)
+        R* stamped = is_map_only_t<F>::value ? stamps_.data() : out->template data<R>();
         hipLaunchKernelGGL((wb_desc_kernel<T, R>), dim3(grid_for(g_.out_cap)), dim3(BLOCK_THREADS), 0, s, table_.view(), states_.data(), runs_.data(),
-                           win_off_.data(), n_fire_.data(), base, desc_.data(), out->template data<R>(), ctl_.data(), g_, flushing);
+                           win_off_.data(), n_fire_.data(), base, desc_.data(), stamped, ctl_.data(), g_, flushing);
         if constexpr (is_map_reduce_t<F>::value) {
             hipLaunchKernelGGL((wb_eval_mapreduce_kernel<T, R, decltype(func_.map), decltype(func_.red)>), dim3(mr_grid_), dim3(BLOCK_THREADS), 0, s, base,
-                               desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, mr_area_.data(), mr_area_tuples_, mr_partials_.data(),
-                               func_.stripes, scratch_.data(), scratch_size_, func_.map, func_.red);
+                               desc_.data(), (const R*)stamped, out->template data<R>(), ctl_.data(), g_.out_cap, mr_area_.data(), mr_area_tuples_,
+                               mr_partials_.data(), func_.stripes, scratch_.data(), scratch_size_, func_.map, func_.red);
         } else if constexpr (is_wave_reduce_t<F>::value) {
             hipLaunchKernelGGL((wb_eval_reduce_kernel<T, R, decltype(func_.lift), decltype(func_.comb)>), dim3(EVAL_GRID), dim3(BLOCK_THREADS), 0, s, base,
                                desc_.data(), out->template data<R>(), ctl_.data(), g_.out_cap, func_.lift, func_.comb);
@@ -1175,6 +1215,8 @@ private:
     DeviceBuffer<char> scratch_;
     DeviceBuffer<T> mr_area_;      // map + reduce evaluation: per-workgroup window laid out stripe by stripe
     DeviceBuffer<R> mr_partials_;
+    DeviceBuffer<R> stamps_;       // MAP stage alone: the pre-stamped result of every fired window
+    uint32_t per_window_ = 1;      // results per fired window
     unsigned mr_grid_ = 0;
     uint32_t mr_area_tuples_ = 0;
     RadixSorter sorter_;

@@ -262,28 +262,79 @@ protected:
     std::shared_ptr<std::vector<gpu::WinCounters>> bcounters_ = std::make_shared<std::vector<gpu::WinCounters>>();
 };
 
-// members shared by the two flat two-stage GPU operators (edge negotiation of the batch path)
-#define WF_TWO_STAGE_GPU_BATCH_PATH(BASE)                                                                                                       \
+// Device first stage (keyed, fed by batches) -> device-to-host + un-batching adapters in the replicas' threads -> host second stage.
+// The reference's own form of the two-stage GPU operators (one stage on the device, the other on the host:
+// wf/pane_farm_gpu.hpp:124-337, wf/win_mapreduce_gpu.hpp:127-360) on the batch path: the first stage's replicas divide the KEYS
+// (on a GPU the panes / stripes of a key are evaluated in parallel inside a replica), its results - numbered per key - come back
+// as tuples for the second-stage replicas on the host.
+template <typename tuple_t, typename result_t>
+inline std::vector<StageSpec> hybrid_two_stage(rt::Graph& g, GPU_Keyed_Window_Stage<tuple_t, result_t>& first, std::shared_ptr<StatsHub> hub, Mode m,
+                                               TwoStageGroup second, const std::string& name, bool ordered) {
+    std::vector<StageSpec> stages = first.build(g, hub, m == Mode::DETERMINISTIC);
+    StageSpec& dev = stages.back();
+    auto adapters = batch_adapter_factory<result_t>(first.slabs());
+    for (rt::Node* r : dev.replicas) {
+        rt::Node* d2h = g.adopt(adapters(EDGE_DEVICE_BATCH));
+        rt::Node* unb = g.adopt(adapters(EDGE_HOST_BATCH));
+        g.connect_fused(r, r->add_out_port(), d2h);
+        g.connect_fused(d2h, d2h->add_out_port(), unb);
+        dev.outputs.push_back(unb);
+    }
+    auto grp = std::make_shared<TwoStageGroup>(std::move(second));
+    StageSpec host;
+    host.name = name + "_stage2";
+    host.routing = COMPLEX;
+    host.internal = true;
+    host.replicas = grp->second;
+    host.outputs = grp->second_outputs.empty() ? grp->second : grp->second_outputs;
+    host.make_emitter = [grp](rt::Graph& gr, size_t) { return grp->second_emitter(gr, 0); };
+    // no ordering node: the first-stage results of a key come from ONE device replica, in order (an ordering by id over the
+    // channels would wait for ids from replicas that never see the key)
+    const size_t second_par = host.replicas.size();
+    stages.push_back(host);
+    if (ordered && second_par > 1) {
+        StageSpec c;
+        c.name = name + "_collector";
+        c.routing = FORWARD;
+        c.internal = true;
+        c.replicas.push_back(g.adopt(new Ordered_Collector<result_t>()));
+        c.make_emitter = [](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<result_t>(1), 1); };
+        stages.push_back(c);
+    }
+    return stages;
+}
+
+// members shared by the two flat two-stage GPU operators (edge negotiation of the batch paths).  flat_: both stages on the
+// device, one keyed stage whose replicas run both; hybrid_: first stage on the device, second on the host (SECOND_GROUP builds
+// the host replicas and the emitter that feeds them)
+#define WF_TWO_STAGE_GPU_BATCH_PATH(BASE, SECOND_GROUP)                                                                                         \
     bool isGPUOperator() const override { return true; }                                                                                        \
-    bool merges_batch_lanes_in_order() const override { return flat_ && !flat_->key_disjoint(); }                                               \
-    bool takes_batch_lanes_one_to_one() const override { return flat_ && flat_->key_disjoint(); }                                               \
-    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override { return flat_ ? flat_->batcher(m) : nullptr; }       \
+    bool merges_batch_lanes_in_order() const override { return in_stage() && !in_stage()->key_disjoint(); }                                     \
+    bool takes_batch_lanes_one_to_one() const override { return in_stage() && in_stage()->key_disjoint(); }                                     \
+    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override {                                                     \
+        return in_stage() && !this->prepared4nesting() ? in_stage()->batcher(m) : nullptr;                                                      \
+    }                                                                                                                                           \
     edge_kind_t output_kind() const override { return batch_path() ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }                                          \
-    bool accepts_input_kind(edge_kind_t k) const override { return flat_ ? true : k == EDGE_TUPLE; }                                            \
+    bool accepts_input_kind(edge_kind_t k) const override { return in_stage() ? true : k == EDGE_TUPLE; }                                       \
     void set_input_kind(edge_kind_t k) override {                                                                                               \
-        if (flat_) flat_->kind = k;                                                                                                             \
+        if (in_stage()) in_stage()->kind = k;                                                                                                   \
     }                                                                                                                                           \
     std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {                                                             \
         return batch_path() ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;                                                        \
     }                                                                                                                                           \
     std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override {                                                                        \
-        return batch_path() ? flat_->build(g, this->hub_, m == Mode::DETERMINISTIC) : BASE::build_stages(g, m);                                 \
+        if (batch_path()) return flat_->build(g, this->hub_, m == Mode::DETERMINISTIC);                                                         \
+        if (hybrid_ && hybrid_->kind != EDGE_TUPLE)                                                                                             \
+            return hybrid_two_stage<tuple_t, result_t>(g, *hybrid_, this->hub_, m, SECOND_GROUP, this->getName(), hybrid_ordered_);             \
+        return BASE::build_stages(g, m);                                                                                                        \
     }                                                                                                                                           \
     std::vector<gpu::WinCounters> getDeviceCounters() const { return *this->bcounters_; }                                                       \
                                                                                                                                                 \
 private:                                                                                                                                        \
     bool batch_path() const { return flat_ && flat_->kind != EDGE_TUPLE; }                                                                      \
-    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_;
+    GPU_Keyed_Window_Stage<tuple_t, result_t>* in_stage() const { return flat_ ? flat_.get() : hybrid_.get(); }                                 \
+    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_, hybrid_;                                                                  \
+    bool hybrid_ordered_ = true;
 
 template <typename tuple_t, typename result_t>
 class Pane_Farm_GPU : public Pane_Farm<tuple_t, result_t>, public TwoStage_GPU_Mixin<tuple_t, result_t> {
@@ -341,71 +392,10 @@ public:
             if (type == TB && o1.carry_capacity == 0) o1.carry_capacity = 1024;
             hybrid_.reset(new GPU_Keyed_Window_Stage<tuple_t, result_t>(factory, pane, pane, triggering_delay, type, plq_parallelism, name + "_plq", cfg, o1,
                                                                        default_routing));
-            hybrid_slabs_ = cfg.pool_slabs;
-            hybrid_wlq_par_ = wlq_parallelism;
             hybrid_ordered_ = ordered;
         }
     }
-    bool isGPUOperator() const override { return true; }
-    bool merges_batch_lanes_in_order() const override { return in_stage() && !in_stage()->key_disjoint(); }
-    bool takes_batch_lanes_one_to_one() const override { return in_stage() && in_stage()->key_disjoint(); }
-    std::function<rt::Node*(size_t, size_t)> input_batcher_factory(Mode m) const override {
-        return in_stage() && !this->prepared4nesting() ? in_stage()->batcher(m) : nullptr;
-    }
-    edge_kind_t output_kind() const override { return flat_ && flat_->kind != EDGE_TUPLE ? EDGE_DEVICE_BATCH : EDGE_TUPLE; }
-    bool accepts_input_kind(edge_kind_t k) const override { return in_stage() ? true : k == EDGE_TUPLE; }
-    void set_input_kind(edge_kind_t k) override {
-        if (in_stage()) in_stage()->kind = k;
-    }
-    std::function<rt::Node*(edge_kind_t)> output_adapter_factory() const override {
-        return flat_ && flat_->kind != EDGE_TUPLE ? batch_adapter_factory<result_t>(flat_->slabs()) : nullptr;
-    }
-    std::vector<StageSpec> build_stages(rt::Graph& g, Mode m) override {
-        if (flat_ && flat_->kind != EDGE_TUPLE) return flat_->build(g, this->hub_, m == Mode::DETERMINISTIC);
-        if (hybrid_ && hybrid_->kind != EDGE_TUPLE) return build_hybrid(g, m);
-        return Pane_Farm<tuple_t, result_t>::build_stages(g, m);
-    }
-    std::vector<gpu::WinCounters> getDeviceCounters() const { return *this->bcounters_; }
-
-private:
-    GPU_Keyed_Window_Stage<tuple_t, result_t>* in_stage() const { return flat_ ? flat_.get() : hybrid_.get(); }
-    // device PLQ stage (keyed, fed by batches) -> adapters -> host WLQ stage
-    std::vector<StageSpec> build_hybrid(rt::Graph& g, Mode m) {
-        std::vector<StageSpec> stages = hybrid_->build(g, this->hub_, m == Mode::DETERMINISTIC);
-        StageSpec& plq = stages.back();
-        auto adapters = batch_adapter_factory<result_t>(hybrid_slabs_);
-        for (rt::Node* r : plq.replicas) {
-            rt::Node* d2h = g.adopt(adapters(EDGE_DEVICE_BATCH));
-            rt::Node* unb = g.adopt(adapters(EDGE_HOST_BATCH));
-            g.connect_fused(r, r->add_out_port(), d2h);
-            g.connect_fused(d2h, d2h->add_out_port(), unb);
-            plq.outputs.push_back(unb);
-        }
-        auto grp = std::make_shared<TwoStageGroup>(this->make_wlq_group(g, this->getName()));
-        StageSpec wlq;
-        wlq.name = this->getName() + "_stage2";
-        wlq.routing = COMPLEX;
-        wlq.internal = true;
-        wlq.replicas = grp->second;
-        wlq.outputs = grp->second_outputs.empty() ? grp->second : grp->second_outputs;
-        wlq.make_emitter = [grp](rt::Graph& gr, size_t) { return grp->second_emitter(gr, 0); };
-        // no ordering node: the pane results of a key come from ONE device replica, in order (an ordering by id over the channels
-        // would wait for pane ids from replicas that never see the key)
-        stages.push_back(wlq);
-        if (hybrid_ordered_ && hybrid_wlq_par_ > 1) {
-            StageSpec c;
-            c.name = this->getName() + "_collector";
-            c.routing = FORWARD;
-            c.internal = true;
-            c.replicas.push_back(g.adopt(new Ordered_Collector<result_t>()));
-            c.make_emitter = [](rt::Graph& gr, size_t) { return single_emitter(gr, new Standard_Emitter<result_t>(1), 1); };
-            stages.push_back(c);
-        }
-        return stages;
-    }
-    std::unique_ptr<GPU_Keyed_Window_Stage<tuple_t, result_t>> flat_, hybrid_;
-    size_t hybrid_slabs_ = 6, hybrid_wlq_par_ = 1;
-    bool hybrid_ordered_ = true;
+    WF_TWO_STAGE_GPU_BATCH_PATH(Pane_Farm<tuple_t WF_COMMA result_t>, this->make_wlq_group(g, this->getName()))
 };
 
 template <typename tuple_t, typename result_t>
@@ -447,9 +437,29 @@ public:
                 return new WinBatchGPU_Node<tuple_t, result_t, mr_t>(mr, p, o, cfg, kind, name, par, idx, closing, hub, counters);
             };
             flat_ = this->make_flat_stage(reduce_parallelism, name, default_routing);
+        } else if constexpr (gpu_map && !gpu::is_wave_reduce_t<map_t>::value) {
+            // The reference's own form - MAP on the device, REDUCE on the host (wf/win_mapreduce_gpu.hpp:127-360) - on the batch
+            // path: a keyed device stage emits the map_parallelism partial results of every window (gpu::map_only; numbered
+            // M * k + m per key, as the M MAP replicas would), the REDUCE replicas on the host combine them
+            auto hub = this->hub_;
+            auto counters = this->bcounters_;
+            const auto mo = gpu::map_only(map, map_parallelism);
+            using mo_t = std::decay_t<decltype(mo)>;
+            const size_t M = map_parallelism;
+            auto factory = [=](const WinParams& p0, const gpu::WinGPUOptions& o, edge_kind_t kind, size_t par, size_t idx) -> rt::Node* {
+                if (counters->size() < par) counters->resize(par);
+                WinParams p = p0;
+                p.role = MAP;
+                p.map_first = 0;
+                p.map_stride = M;
+                return new WinBatchGPU_Node<tuple_t, result_t, mo_t>(mo, p, o, cfg, kind, name + "_map", par, idx, closing, hub, counters);
+            };
+            hybrid_.reset(new GPU_Keyed_Window_Stage<tuple_t, result_t>(factory, win_len, slide_len, triggering_delay, type, reduce_parallelism,
+                                                                       name + "_map", cfg, opt, default_routing));
+            hybrid_ordered_ = ordered;
         }
     }
-    WF_TWO_STAGE_GPU_BATCH_PATH(Win_MapReduce<tuple_t WF_COMMA result_t>)
+    WF_TWO_STAGE_GPU_BATCH_PATH(Win_MapReduce<tuple_t WF_COMMA result_t>, this->make_reduce_group(g, this->getName()))
 };
 
 // ---- operators -------------------------------------------------------------------

@@ -43,11 +43,11 @@ protected:
         const uint64_t win = win_, slide = slide_, delay = delay_;
         const size_t M = map_par_, R = reduce_par_;
         const win_type_t type = type_;
-        group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix) {
+        group_factory_ = [=](rt::Graph& g, const NestCtx& ctx, const std::string& prefix, bool with_map) {
             TwoStageGroup grp;
             const uint64_t my_slide = slide * ctx.slide_mult;
             // ---- MAP ------------------------------------------------------------
-            for (size_t i = 0; i < M; i++) {
+            for (size_t i = 0; with_map && i < M; i++) {
                 WinParams p;
                 p.win_len = win;
                 p.slide_len = my_slide;
@@ -102,10 +102,10 @@ public:
             fatal_error("Win_MapReduce [" + name_ + "] has been prepared for nesting, it cannot be added directly to a MultiPipe");
         NestCtx ctx;
         ctx.slide_outer = slide_;
-        std::vector<TwoStageGroup> groups{group_factory_(g, ctx, name_)};
+        std::vector<TwoStageGroup> groups{group_factory_(g, ctx, name_, true)};
         return assemble_two_stage<tuple_t, result_t>(g, groups, type_, name_, nullptr, ordered_);
     }
-    TwoStageGroup make_group(rt::Graph& g, const NestCtx& ctx, const std::string& prefix) override { return group_factory_(g, ctx, prefix); }
+    TwoStageGroup make_group(rt::Graph& g, const NestCtx& ctx, const std::string& prefix) override { return group_factory_(g, ctx, prefix, true); }
     uint64_t getWinLen() const override { return win_; }
     uint64_t getSlideLen() const override { return slide_; }
     uint64_t getTriggeringDelay() const override { return delay_; }
@@ -117,6 +117,16 @@ public:
     size_t getREDUCEParallelism() const { return reduce_par_; }
     void setPrepared4Nesting() { prepared4nesting_ = true; }
 
+protected:
+    // the REDUCE stage alone (its replicas and the emitter that feeds them): for operators that compute the partial results by
+    // other means (Win_MapReduce_GPU fed by batches: one keyed device stage instead of the M MAP replicas)
+    TwoStageGroup make_reduce_group(rt::Graph& g, const std::string& prefix) {
+        NestCtx ctx;
+        ctx.slide_outer = slide_;
+        return group_factory_(g, ctx, prefix, false);
+    }
+    bool prepared4nesting() const { return prepared4nesting_; }
+
 private:
     std::string name_;
     uint64_t win_, slide_, delay_;
@@ -125,7 +135,7 @@ private:
     bool ordered_;
     opt_level_t opt_;
     bool prepared4nesting_ = false;
-    std::function<TwoStageGroup(rt::Graph&, const NestCtx&, const std::string&)> group_factory_;
+    std::function<TwoStageGroup(rt::Graph&, const NestCtx&, const std::string&, bool with_map)> group_factory_;
 };
 
 }  // namespace wf
