@@ -334,6 +334,8 @@ __device__ __forceinline__ uint32_t wb_count_below(At at, uint32_t n, uint64_t x
     return lo;
 }
 
+constexpr uint32_t WB_GATHER_CHUNK = 1024;  // carried tuples copied by one wave
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK_THREADS)
     wb_gather_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, const WinKeyState* states, WinRun* runs,
@@ -347,15 +349,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     // tuples of its key, which are in order too: the position of every tuple in the segment is its own index plus the number
     // of tuples of the other sequence that go before it (carried tuples first on ties) - one comparison when the run begins
     // after the last carried tuple, a binary search in the overlap otherwise.  No thread moves more than one tuple.
-    // (a) the carried tuples, one wave per run
+    // (a) the carried tuples, WB_GATHER_CHUNK of them per wave (a long triggering delay makes a key carry tens of thousands
+    //     of tuples: one wave per run took 0.5 ms per batch for 16 keys x 20 000 carried tuples, profiles/r3_two_stage_hybrid)
     const uint32_t waves_total = gridDim.x * (BLOCK_THREADS / WAVE);
-    for (uint32_t r = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); r < n_runs; r += waves_total) {
+    const uint32_t chunks = (g.carry_cap + WB_GATHER_CHUNK - 1) / WB_GATHER_CHUNK;
+    const uint64_t units = (uint64_t)n_runs * chunks;
+    for (uint64_t u = blockIdx.x * (BLOCK_THREADS / WAVE) + wave_id(); u < units; u += waves_total) {
+        const uint32_t r = (uint32_t)(u / chunks), c = (uint32_t)(u % chunks);
         const uint32_t off = work_off[r], clen = runs[r].carry_len, start = runs[r].start, len = runs[r].len;
-        if (lane_id() == 0) runs[r].seg_off = off;
+        if (c == 0 && lane_id() == 0) runs[r].seg_off = off;
+        const uint32_t k0 = c * WB_GATHER_CHUNK;
+        if (k0 >= clen) continue;
+        const uint32_t k1 = clen - k0 < WB_GATHER_CHUNK ? clen : k0 + WB_GATHER_CHUNK;
         const T* src = carry + (size_t)runs[r].dense * g.carry_cap;
-        const bool merge = !g.renumber && len > 0 && clen > 0 && unsorted_stamp[runs[r].slot] != batch_no;
+        const bool merge = !g.renumber && len > 0 && unsorted_stamp[runs[r].slot] != batch_no;
         const uint64_t r_first = merge ? win_ord(data[sidx[start]], g.is_tb) : 0;
-        for (uint32_t k = lane_id(); k < clen; k += WAVE) {
+        for (uint32_t k = k0 + lane_id(); k < k1; k += WAVE) {
             uint32_t before = 0;
             if (merge) {
                 const uint64_t o = win_ord(src[k], g.is_tb);
