@@ -23,6 +23,7 @@ line winseq_64ki --steps 10 --warmup 2 --pipeline win_seq --keys 65536
 line shared64_default --steps 5 --warmup 1 --keys 64 --shared-keys --tuples-per-step 134217728 --device-probe-steps 0
 line shared1ki_default --steps 5 --warmup 1 --keys 1024 --shared-keys --tuples-per-step 134217728 --device-probe-steps 0
 line shared64_deterministic --steps 5 --warmup 1 --keys 64 --shared-keys --deterministic --tuples-per-step 134217728 --device-probe-steps 0
+line shared1ki_deterministic --steps 5 --warmup 1 --keys 1024 --shared-keys --deterministic --tuples-per-step 134217728 --device-probe-steps 0
 line flagship_keyby --steps 20 --warmup 3 --parallelism keyby
 line flagship_64keys --steps 10 --warmup 2 --keys 64
 line flagship_8keys --steps 10 --warmup 2 --keys 8
@@ -50,7 +51,7 @@ win() { echo "== bench_win_gpu $*" >&2; timeout -k 10 60 apps/bin/bench_win_gpu 
 : > "$OUT/win.txt"
 # tuple-fed (CPU Source -> GPU window operator: the reference's programming model; the producers fill batches), DETERMINISTIC and DEFAULT
 for op in kf_gpu wf_gpu pf_gpu wmr_gpu pf_gg wmr_gg kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536; done
-for op in kf_gpu wf_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536 -D; done
+for op in kf_gpu wf_gpu pf_gpu wmr_gpu pf_gg wmr_gg kff_gpu; do win -o $op -s 4 -n 4 -k 64 -b 65536 -D; done
 # batch-fed
 for op in kf_gpu wf_gpu pf_gpu wmr_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 256 -b 131072 -B; done
 for op in kf_gpu wf_gpu kff_gpu; do win -o $op -s 4 -n 4 -k 4096 -b 4096 -B; done
