@@ -552,6 +552,53 @@ def test_key_ffat_huge_runs_time_based_with_triggering_delay(ext, win, slide, de
         assert got[k][0] == pytest.approx(s, abs=1e-9), k
 
 
+def lagging_lanes_stream(n_keys, lanes, piece, rounds, lags, seed):
+    """Batches as the device KeyBy of a DEFAULT graph hands them to a replica: one piece per lane and round, every lane in
+    timestamp order (every key ticks once per time unit in every lane), lane l `lags[l]` rounds behind in arrival - the time of
+    a key jumps forth and back by lag * piece / n_keys between the pieces of a batch."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for r in range(rounds + max(lags)):
+        for l in range(lanes):
+            p = r - lags[l]
+            if p < 0 or p >= rounds:
+                continue
+            j = np.arange(p * piece, (p + 1) * piece)
+            blk = np.zeros((piece, 5), dtype=np.int64)
+            blk[:, 0] = (j % n_keys) * 7919 + 3
+            blk[:, 2] = j // n_keys
+            rows.append(blk)
+    t = np.concatenate(rows)
+    t[:, 1] = np.arange(len(t))
+    vals = rng.integers(-50, 50, len(t)).astype(np.float64)
+    t[:, 3] = vals.view(np.int64)
+    t[:, 4] = np.float64(1.0).view(np.int64)
+    return t, vals
+
+
+@pytest.mark.parametrize("presort", ["0", "1", "2"])
+@pytest.mark.parametrize("n_keys,lanes,piece,rounds,lags", [
+    (4, 4, 4096, 10, (0, 3, 1, 6)),     # runs of 4096 tuples of a key per batch (huge-run path when in order), jumps of 300-600 quanta
+    (64, 4, 4096, 8, (0, 2, 5, 1)),     # runs of 256 (wave-per-run bulk path), jumps of 13-32 quanta ... and of more than 64:
+    (16, 8, 2048, 8, (0, 7, 2, 5, 1, 6, 3, 4)),
+])
+def test_key_ffat_lanes_that_lag_behind_each_other(ext, n_keys, lanes, piece, rounds, lags, presort, monkeypatch):
+    """A triggering delay that covers the lag between the lanes keeps thousands of quanta open; the pieces of a batch make a
+    key's time jump by hundreds of quanta.  Nothing is late, so the plain window sums are the oracle - with the (key, pane)
+    pre-sort off (arrival order: the run is out of timestamp order), adaptive, and always on (the run is in order and jumps)."""
+    monkeypatch.setenv("WF_TS_PRESORT", presort)
+    win, slide = 80, 10
+    t, vals = lagging_lanes_stream(n_keys, lanes, piece, rounds, lags, seed=n_keys + lanes)
+    delay = (max(lags) + 2) * piece // n_keys
+    res, ctr = ext.key_ffat_run(t, win, slide, delay, True, 2 * n_keys, lanes * piece, 1 << 20)
+    assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
+    got = unpack(res)
+    exp = oracle_tb(t, vals, win, slide)
+    assert len(res) == len(got) == len(exp)
+    for k, s in exp.items():
+        assert got[k][0] == pytest.approx(s, abs=1e-9), k
+
+
 def test_key_ffat_huge_runs_with_disorder_fall_back(ext, monkeypatch):
     """a hot key whose tuples are not in timestamp order (delay 0: the late ones are dropped, by the same rules as a short run;
     without the (key, pane) pre-sort, which would make the tuples of a batch arrive in order)"""
