@@ -626,6 +626,35 @@ public:
         }
     }
 
+    // Several host batches queued on one channel: the replica has fallen behind its producer.  Small ones are uploaded into
+    // ONE device batch (in arrival order) and go through the kernels together - a batch costs ~10 launches whatever its size
+    // (flagship at 16 Ki batches: the replica thread was 97 % busy issuing them, profiles/r3_small_batch).  A batch that
+    // carries a token in its header (a marker batch, the benchmark's step barrier) ends its group: its header fields go to
+    // the merged batch, nothing is reordered.
+    void svc_bulk(void** msgs, size_t n, int ch) override {
+        if (in_kind_ != EDGE_HOST_BATCH || n < 2 || gpu::coalesce_tuples() == 0) {
+            for (size_t i = 0; i < n; i++) svc(msgs[i], ch);
+            return;
+        }
+        size_t i = 0;
+        while (i < n) {
+            gpu::Batch* first = static_cast<gpu::Batch*>(msgs[i]);
+            const size_t room = coalesce_capacity(first->capacity);
+            size_t k = 1, tuples = first->host_hdr.count;
+            while (i + k < n && !has_token(static_cast<gpu::Batch*>(msgs[i + k - 1]))) {
+                gpu::Batch* next = static_cast<gpu::Batch*>(msgs[i + k]);
+                if (tuples + next->host_hdr.count > room || next->capacity != first->capacity) break;
+                tuples += next->host_hdr.count;
+                k++;
+            }
+            if (k == 1)
+                ship(first);
+            else
+                ship(reinterpret_cast<gpu::Batch**>(msgs + i), k);
+            i += k;
+        }
+    }
+
     // end of stream: the partial batch goes through the same kernels (the
     // reference falls back to the CPU here, wf/map_gpu_node.hpp:502-604)
     void flush() override {
@@ -665,6 +694,9 @@ protected:
         s.bytes_copied_dh = bytes_dh_;
     }
     hipStream_t stream() const { return cur_stream_ ? cur_stream_ : stream_->get(); }
+    // how many of its producers' host batches one device input batch may hold (see svc_bulk): what an operator sizes per
+    // input batch on the user's word (an output capacity) grows by this factor
+    size_t input_scale() const { return input_scale_; }
     // hand an input slab back after the work enqueued so far (whichever GPU's context owns the slab)
     void release_input(gpu::Batch* b) { gpu::release_after(b, stream(), cfg_.gpu_id, foreign_); }
     // record completion on the batch and pass it downstream
@@ -711,23 +743,56 @@ private:
     }
     // host batch -> device batch (async), then the operator's kernels: on the replica's compute stream, or with
     // WF_UPLOAD_STREAMS=n on a shared upload stream, the kernels following once the copy is known to be complete
-    void ship(gpu::Batch* h) {
+    // tuples a device input slab holds: the producer's batch capacity, or a multiple of it up to WF_COALESCE_TUPLES when the
+    // replica has an input ring to find several batches in (see svc_bulk)
+    size_t coalesce_capacity(size_t host_capacity) const {
+        const size_t lim = gpu::coalesce_tuples();
+        if (!this->has_input_rings() || host_capacity == 0 || lim < 2 * host_capacity) return host_capacity;
+        return (lim / host_capacity) * host_capacity;
+    }
+    static bool has_token(const gpu::Batch* b) {
+        const uint64_t* r = b->host_hdr.reserved;
+        return (r[0] | r[1] | r[2] | r[3]) != 0;
+    }
+    void ship(gpu::Batch* h) { ship(&h, 1); }
+    void ship(gpu::Batch** hs, size_t k) {
         gpu::TraceRange tr("wf:ship_batch");
+        gpu::Batch* h = hs[0];
         if (!dev_in_pool_) {
-            dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), h->capacity, cfg_.pool_slabs));
+            dev_in_pool_.reset(new gpu::BatchPool(gpu::MemKind::DEVICE, cfg_.gpu_id, sizeof(in_t), coalesce_capacity(h->capacity), cfg_.pool_slabs));
+            input_scale_ = std::max<size_t>(1, coalesce_capacity(h->capacity) / std::max<size_t>(1, h->capacity));
             // (a replica fused onto its producer is never polled between inputs: its uploads stay in its compute stream)
             const size_t ups = this->has_input_rings() ? gpu::upload_streams(this->context.getParallelism()) : 0;
             upload_stream_ = ups == 0 ? stream() : gpu::shared_copy_stream(cfg_.gpu_id, 1 + (int)(this->context.getReplicaIndex() % ups));
         }
-        if (h->capacity > dev_in_pool_->capacity()) gpu::failwith("GPU operator: a batch larger than the first one received (producers with different batch lengths?)");
+        gpu::BatchHeader merged = h->host_hdr;
+        for (size_t i = 1; i < k; i++) {
+            const gpu::BatchHeader& o = hs[i]->host_hdr;
+            merged.count += o.count;
+            merged.watermark = std::max(merged.watermark, o.watermark);
+            if (o.created_ns != 0 && (merged.created_ns == 0 || o.created_ns < merged.created_ns)) merged.created_ns = o.created_ns;
+            for (int r = 0; r < 4; r++)
+                if (o.reserved[r] != 0) merged.reserved[r] = o.reserved[r];  // (only the last batch of a group carries tokens)
+        }
+        if (merged.count > dev_in_pool_->capacity()) gpu::failwith("GPU operator: a batch larger than the first one received (producers with different batch lengths?)");
         gpu::Batch* d = dev_in_pool_->acquire(upload_stream_);
-        *h->header() = h->host_hdr;  // the header travels in the slab
-        const size_t bytes = h->bytes_used();
-        WF_HIP_CHECK(hipMemcpyAsync(d->slab, h->slab, bytes, hipMemcpyHostToDevice, upload_stream_));
-        bytes_hd_ += bytes;
-        d->host_hdr = h->host_hdr;
+        *h->header() = merged;  // the header travels in the slab
+        size_t off = 0;
+        for (size_t i = 0; i < k; i++) {
+            const size_t data_bytes = (size_t)hs[i]->host_hdr.count * sizeof(in_t);
+            if (i == 0) {
+                WF_HIP_CHECK(hipMemcpyAsync(d->slab, h->slab, sizeof(gpu::BatchHeader) + data_bytes, hipMemcpyHostToDevice, upload_stream_));
+                bytes_hd_ += sizeof(gpu::BatchHeader);
+            } else if (data_bytes > 0) {
+                WF_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(d->template data<in_t>()) + off, hs[i]->template data<in_t>(), data_bytes,
+                                            hipMemcpyHostToDevice, upload_stream_));
+            }
+            off += data_bytes;
+            bytes_hd_ += data_bytes;
+        }
+        d->host_hdr = merged;
         d->count_on_host = true;
-        gpu::release_after(h, upload_stream_, cfg_.gpu_id, foreign_);  // the pinned slab may belong to another GPU's context
+        for (size_t i = 0; i < k; i++) gpu::release_after(hs[i], upload_stream_, cfg_.gpu_id, foreign_);  // the pinned slab may belong to another GPU's context
         reaper_.tick(stream());
         if (upload_stream_ == stream()) {  // uploads in the compute stream: stream order is all the kernels need
             process_device(d);
@@ -755,6 +820,7 @@ private:
         }
     }
 
+    size_t input_scale_ = 1;
     hipStream_t upload_stream_ = nullptr;
     hipStream_t cur_stream_ = nullptr;  // the producer's stream, once inherited (see svc)
     bool inherit_stream_ = gpu::inherit_streams();

@@ -253,6 +253,16 @@ inline bool pool_wait_on_host() {
     }();
     return h;
 }
+// WF_COALESCE_TUPLES=n: a GPU replica that finds several small host batches queued uploads them into ONE device batch of at
+// most n tuples (default 131072; 0: never) - the launches of a batch cost the same for 16 Ki tuples as for 128 Ki, so a
+// replica that has fallen behind catches up with fewer, larger batches, and one that keeps up sees single batches
+inline size_t coalesce_tuples() {
+    static const size_t v = [] {
+        const char* e = std::getenv("WF_COALESCE_TUPLES");
+        return e ? (size_t)std::atoll(e) : (size_t)131072;
+    }();
+    return v;
+}
 // WF_INHERIT_STREAMS=0: a GPU replica fused onto its producer keeps a stream of its own instead of continuing on the producer's
 inline bool inherit_streams() {
     static const bool h = [] {

@@ -193,13 +193,12 @@ private:
                         // service time is measured per bulk (two clock reads per up to 64 messages), successors fused in
                         // this thread included
                         const uint64_t t0 = now_ns();
-                        for (size_t i = 0; i < n; i++) {
-                            if (buf[i] == eos_token()) {
-                                ended = true;  // producer never pushes after EOS
-                                break;
-                            }
-                            head->counters_.inputs++;
-                            head->svc(buf[i], ch);
+                        size_t m = 0;
+                        while (m < n && buf[m] != eos_token()) m++;
+                        ended = m < n;  // producer never pushes after EOS
+                        if (m > 0) {
+                            head->counters_.inputs += m;
+                            head->svc_bulk(buf, m, ch);
                         }
                         head->counters_.busy_ns += now_ns() - t0;
                     }

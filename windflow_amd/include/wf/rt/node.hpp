@@ -93,6 +93,11 @@ public:
     virtual void svc_init() {}
     // process one message received on input channel `channel`
     virtual void svc(void* /*msg*/, int /*channel*/) {}
+    // the messages the thread found queued on one input channel, oldest first (head nodes only): a node that can do several
+    // at once for less than the sum (a GPU replica coalescing small host batches into one device batch) overrides this
+    virtual void svc_bulk(void** msgs, size_t n, int channel) {
+        for (size_t i = 0; i < n; i++) svc(msgs[i], channel);
+    }
     // source nodes: produce some output, return false when the stream is over
     virtual bool generate() { return false; }
     virtual bool is_source() const { return false; }
