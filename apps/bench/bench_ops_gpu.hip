@@ -15,7 +15,7 @@
 //   -o filter_stateful   keyed filter on the same state: keeps tuples above the running average
 //   -o keyby             device KeyBy only (scattering study): S lanes re-partitioned into N
 //
-//   bench_ops_gpu -o <op> [-s sources] [-n operator replicas] [-k keys] [-b batch length] [-t seconds]
+//   bench_ops_gpu -o <op> [-s sources] [-n operator replicas] [-k keys] [-b batch length] [-t seconds] [-i batches in flight per source (6)]
 //
 // prints one line:  <op> sources=S replicas=N keys=K batch=B : X tuples/s (Y results/s), elapsed Z s
 #include <execinfo.h>
@@ -168,8 +168,9 @@ int main(int argc, char** argv) {
     size_t sources = 4, replicas = 0, keys = 1 << 14, batch = 1 << 17;
     double seconds = 3.0;
     bool device_source = false;
+    size_t inflight = 6;  // pinned slabs per source: batches that can be queued in front of a replica
     int c;
-    while ((c = getopt(argc, argv, "o:s:n:k:b:t:d")) != -1) {
+    while ((c = getopt(argc, argv, "o:s:n:k:b:t:di:")) != -1) {
         switch (c) {
             case 'o': op = optarg; break;
             case 's': sources = std::strtoull(optarg, nullptr, 10); break;
@@ -178,9 +179,10 @@ int main(int argc, char** argv) {
             case 'b': batch = std::strtoull(optarg, nullptr, 10); break;
             case 't': seconds = std::atof(optarg); break;
             case 'd': device_source = true; break;
+            case 'i': inflight = std::strtoull(optarg, nullptr, 10); break;
             default:
                 std::cout << argv[0] << " -o map_stateless|filter_stateless|map_stateful|map_sum|map_scan|filter_stateful|keyby|win_agg [-s sources] [-n replicas] "
-                          << "[-k keys] [-b batch] [-t seconds] [-d (generate on the device)]" << std::endl;
+                          << "[-k keys] [-b batch] [-t seconds] [-d (generate on the device)] [-i batches in flight per source]" << std::endl;
                 return 0;
         }
     }
@@ -227,7 +229,7 @@ int main(int argc, char** argv) {
                   })
                   .build_unique();
     } else {
-        src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).build_unique();
+        src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).withInFlightBatches(inflight).build_unique();
     }
     MultiPipe& mp = graph.add_source(*src);
     std::unique_ptr<Basic_Operator> oper;
