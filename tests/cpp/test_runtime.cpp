@@ -6,7 +6,9 @@
 //   test_runtime            run every case, exit 0 iff all pass
 //   test_runtime illegal N  run illegal-topology case N (must die with a WindFlow Error)
 #include "../../windflow_amd/csrc/bench_common.hpp"  // SkewBound (the benchmark sources that share keys)
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <iostream>
@@ -117,6 +119,41 @@ static void test_graph() {
     CHECK(cnt == N);
     CHECK(sum == N * (N - 1) / 2 + 11 * N);
     CHECK(eos == 3);  // one notification per input channel
+}
+
+// svc_bulk: a head node sees the messages found queued on a channel together, in order, never the end-of-stream token, and
+// every message exactly once (what a GPU replica builds its coalescing of small host batches on)
+struct BulkCollector : rt::Node {
+    long next = 0, groups = 0, largest = 0, total = 0;
+    bool in_order = true;
+    void svc(void*, int) override { in_order = false; }  // (a head node is always fed through svc_bulk)
+    void svc_bulk(void** msgs, size_t n, int ch) override {
+        if (ch != 0 || n == 0) in_order = false;
+        groups++;
+        largest = std::max<long>(largest, (long)n);
+        for (size_t i = 0; i < n; i++) {
+            long* v = static_cast<long*>(msgs[i]);
+            if (*v != next++) in_order = false;
+            total++;
+            delete v;
+        }
+        if (groups % 50 == 0) this_thread::sleep_for(chrono::microseconds(200));  // fall behind: the ring fills up
+    }
+};
+static void test_svc_bulk() {
+    rt::RuntimeConfig cfg;
+    cfg.queue_capacity = 64;
+    rt::Graph g(cfg);
+    const long N = 100000;
+    auto* p = g.adopt(new Producer(N));
+    auto* c = static_cast<BulkCollector*>(g.adopt(new BulkCollector()));
+    g.connect_queue(p, p->add_out_port(), c);
+    g.run();
+    g.wait();
+    CHECK(c->in_order);
+    CHECK(c->total == N);
+    CHECK(c->groups <= N);
+    CHECK(c->largest > 1 && c->largest <= 64);  // the consumer did fall behind, and a group never exceeds the bulk pop
 }
 
 // blocking mode: consumers sleep on their futex when the rings are empty, producers when a ring is full
@@ -531,6 +568,7 @@ int main(int argc, char** argv) {
     test_skew_bound();
     test_spsc();
     test_graph();
+    test_svc_bulk();
     test_graph_blocking();
     test_string_keys();
     test_flatfat();
