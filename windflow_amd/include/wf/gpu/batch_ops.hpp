@@ -794,6 +794,9 @@ private:
         d->count_on_host = true;
         for (size_t i = 0; i < k; i++) gpu::release_after(hs[i], upload_stream_, cfg_.gpu_id, foreign_);  // the pinned slab may belong to another GPU's context
         reaper_.tick(stream());
+        // (the copy stream of a lone replica needs the same care: nobody else ever synchronises it, and HIP's host-side
+        // bookkeeping of its copies and event records grew by ~12 MB/s - apps/bench/r3_check33.sh)
+        if (upload_stream_ != stream()) upload_reaper_.tick(upload_stream_);
         if (upload_stream_ == stream()) {  // uploads in the compute stream: stream order is all the kernels need
             process_device(d);
             WF_HIP_CHECK(hipGetLastError());
@@ -827,7 +830,7 @@ private:
     std::unique_ptr<gpu::Event> handoff_;
     gpu::ForeignReleaser foreign_;
     std::deque<gpu::Batch*> uploading_;
-    gpu::StreamReaper reaper_;
+    gpu::StreamReaper reaper_, upload_reaper_;
     std::unique_ptr<gpu::Stream> stream_;
     std::unique_ptr<gpu::BatchPool> staging_pool_;
     std::unique_ptr<gpu::BatchPool> dev_in_pool_;
