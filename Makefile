@@ -11,7 +11,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O2 -std=c++17 -mllvm -unroll-runtime $(INC)
 CPU_BINS := tests/cpp/bin/smoke_basic_ops tests/cpp/bin/test_mp_windows tests/cpp/bin/test_graphs tests/cpp/bin/test_runtime \
             tests/cpp/bin/test_api_variants apps/bin/ysb_kf apps/bin/ysb_wmr apps/bin/bench_cpu apps/bin/example_wordcount
 GPU_BINS := tests/cpp/bin/test_mp_windows_gpu tests/cpp/bin/test_mp_windows_gpu_fixedkey tests/cpp/bin/test_gpu_keyed apps/bin/ysb_gpu apps/bin/bench_ops_gpu apps/bin/bench_win_gpu \
-            apps/bin/example_gpu_pipeline
+            apps/bin/example_gpu_pipeline apps/bin/example_gpu_pane_farm
 HEADERS  := $(shell find windflow_amd/include windflow_amd/csrc tests/cpp apps/ysb -name '*.hpp')
 
 all: cpu gpu
@@ -44,6 +44,9 @@ apps/bin/example_wordcount: examples/wordcount_windows.cpp $(HEADERS)
 	@mkdir -p $(@D)
 	$(CXX) $(CXXFLAGS) $< -o $@ -pthread
 apps/bin/example_gpu_pipeline: examples/gpu_pipeline.hip $(HEADERS)
+	@mkdir -p $(@D)
+	$(HIPCC) $(HIPFLAGS) $< -o $@ -lpthread
+apps/bin/example_gpu_pane_farm: examples/gpu_pane_farm.hip $(HEADERS)
 	@mkdir -p $(@D)
 	$(HIPCC) $(HIPFLAGS) $< -o $@ -lpthread
 

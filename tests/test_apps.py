@@ -87,3 +87,17 @@ def test_ysb_gpu_dist_rccl_single_rank():
     got = run_app("ysb_gpu_dist", ["-e", 1_000_000, "-p", 10, "-n", 2, "-m", 2, "-b", 8192, "-d", 30_000_000, "-t", "rccl", "-i", "/tmp/wf_test_rccl_id"],
                   hip=True, extra=wfbuild.RCCL_FLAGS)
     assert got == expected(1_000_000, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,expect", [("gpu_pipeline", r"\d+ windows, hottest reading [\d.]+ F"),
+                                         ("gpu_pane_farm", r"8000 windows, 388322956 shares counted")  # (NumPy: sum over all windows)])
+def test_gpu_examples_run(name, expect):
+    """examples/: the device pipeline (Filter_GPU -> Map_GPU -> Key_FFAT_GPU) and the reference-style program (CPU Source ->
+    Pane_Farm_GPU with the PLQ on the device, the WLQ on the host and 16-byte symbol keys -> CPU Sink; it checks its own
+    window count)"""
+    src = os.path.join(ROOT, "examples", name + ".hip")
+    exe = wfbuild.build_cpp(src, os.path.join(ROOT, "apps", "bin", "example_" + name), hip=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=110, env=dict(os.environ, WF_QUIET="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert re.search(expect, r.stdout), r.stdout[-2000:]

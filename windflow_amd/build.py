@@ -117,6 +117,7 @@ PROGRAMS = [
     ("apps/bench/bench_cpu.cpp", "apps/bin/bench_cpu", False),
     ("examples/wordcount_windows.cpp", "apps/bin/example_wordcount", False),
     ("examples/gpu_pipeline.hip", "apps/bin/example_gpu_pipeline", True),
+    ("examples/gpu_pane_farm.hip", "apps/bin/example_gpu_pane_farm", True),
 ]
 
 
