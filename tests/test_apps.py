@@ -91,7 +91,7 @@ def test_ysb_gpu_dist_rccl_single_rank():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,expect", [("gpu_pipeline", r"\d+ windows, hottest reading [\d.]+ F"),
-                                         ("gpu_pane_farm", r"8000 windows, 388322956 shares counted")  # (NumPy: sum over all windows)])
+                                         ("gpu_pane_farm", r"8000 windows, 388322956 shares counted")])  # (NumPy: sum over all windows)
 def test_gpu_examples_run(name, expect):
     """examples/: the device pipeline (Filter_GPU -> Map_GPU -> Key_FFAT_GPU) and the reference-style program (CPU Source ->
     Pane_Farm_GPU with the PLQ on the device, the WLQ on the host and 16-byte symbol keys -> CPU Sink; it checks its own
