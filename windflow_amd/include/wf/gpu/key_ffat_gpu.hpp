@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
     ffat_update_kernel(const BatchHeader* hdr, const T* data, SortedSel sel, FFATRecords<R> recs, R* trees,
                        FFATGeometry g, R* out, uint32_t* out_count, FFATCounters* ctr, uint32_t* long_heads,
                        uint32_t* n_long, L lift, C comb, uint32_t huge_mode = 0, uint32_t huge_len = 0, uint32_t* huge_heads = nullptr,
-                       uint32_t* n_huge = nullptr, volatile uint32_t* huge_seen = nullptr, uint32_t batch_no = 0) {
+                       uint32_t* n_huge = nullptr, volatile uint32_t* huge_seen = nullptr, uint32_t batch_no = 0, uint32_t long_run = FFAT_LONG_RUN) {
     const uint32_t n = hdr->count;
     // a batch without a second tuple of any key was not sorted: every tuple is a run of its own, in any order
     const uint32_t* sslot = sel.keys();
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS)
             atomicAdd(&ctr->table_full, 1u);
             continue;
         }
-        if (i + FFAT_LONG_RUN - 1 < n && sslot[i + FFAT_LONG_RUN - 1] == slot) {
+        if (i + long_run - 1 < n && sslot[i + long_run - 1] == slot) {
             // huge_mode 1: a run long enough to be spread over the chip is only reported (the host then switches the
             // huge-run kernels on for the batches that follow); 2: it is left to them (ffat_huge_gpu.hpp)
             const bool huge = huge_mode != 0 && i + huge_len - 1 < n && sslot[i + huge_len - 1] == slot;
@@ -964,7 +964,8 @@ public:
         idx_.resize(batch_cap_);
         counters_.resize(1);
         WF_HIP_CHECK(hipMemsetAsync(counters_.data(), 0, sizeof(FFATCounters), init.get()));
-        long_heads_.resize(batch_cap_ / FFAT_LONG_RUN + 2);
+        if (const char* e = std::getenv("WF_FFAT_LONG_RUN")) long_run_ = (uint32_t)std::max(2, std::atoi(e));
+        long_heads_.resize(batch_cap_ / long_run_ + 2);
         n_long_.resize(2);  // [0] long runs, [1] huge runs of the batch in flight
         WF_HIP_CHECK(hipMemsetAsync(n_long_.data(), 0, 2 * sizeof(uint32_t), init.get()));
         // huge runs (ffat_huge_gpu.hpp): count-based windows, or time-based ones whose ring of open quanta is not enormous
@@ -1092,7 +1093,7 @@ private:
             hipLaunchKernelGGL((ffat_update_kernel<T, R, L, C>), dim3(grid), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(),
                                sel, recs(), trees_.data(), g_,
                                out->template data<R>(), out->device_count_ptr(), counters_.data(), long_heads_.data(), n_long_.data(), lift_,
-                               comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_);
+                               comb_, huge_mode, FFAT_HUGE_RUN, huge_heads_.data(), n_long_.data() + 1, huge_seen_, batch_no_, long_run_);
             if (huge_mode == 2) {
                 hipLaunchKernelGGL((ffat_huge_setup_kernel<T, R>), dim3(1), dim3(BLOCK_THREADS), 0, s, in->header(), in->template data<T>(), sorted.keys,
                                    sorted.vals, recs(), g_, huge_heads_.data(), n_long_.data() + 1, huge_runs_.data(), huge_ctl_.data(),
@@ -1121,7 +1122,7 @@ private:
                                    out->template data<R>(), counters_.data(), table_.view(), comb_);
             }
             // at most upper / FFAT_LONG_RUN long runs; a wave each, 4 waves per block (exits at once when there is none)
-            const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / FFAT_LONG_RUN / (BLOCK_THREADS / WAVE) + 1));
+            const unsigned lgrid = (unsigned)std::min<size_t>(512, std::max<size_t>(1, upper / long_run_ / (BLOCK_THREADS / WAVE) + 1));
             if (long_layout_.bulk == 2)
                 hipLaunchKernelGGL((ffat_update_long_kernel<true, T, R, L, C>), dim3(lgrid), dim3(BLOCK_THREADS), long_lds_bytes_, s, in->header(),
                                    in->template data<T>(), sorted.keys, sorted.vals, recs(), trees_.data(),
@@ -1208,6 +1209,7 @@ private:
     size_t flush_n_ = 0;
     DeviceBuffer<FFATCounters> counters_;
     DeviceBuffer<uint32_t> long_heads_, n_long_;
+    uint32_t long_run_ = FFAT_LONG_RUN;  // (WF_FFAT_LONG_RUN: experiments)
     FFATLongLayout<R> long_layout_{0, 0, 0};
     // huge runs
     static constexpr uint32_t HUGE_LINGER_BATCHES = 256;  // batches without a huge run after which their kernels are switched off

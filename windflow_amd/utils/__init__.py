@@ -27,6 +27,7 @@ RUNTIME_ENV = {
     "WF_EDGE_WAIT": "host | device: where a consumer waits for the event of a batch produced by another stream (device)",
     "WF_WIN_QUIET_RUNS": "0: the non-incremental GPU window engine gathers every run of a batch into the work buffer, also the short ones that fire no window (1: those are appended to the key's carry area in place)",
     "WF_COALESCE_TUPLES": "a GPU replica that finds several small host batches queued uploads them into one device batch of at most n tuples; 0: never (131072)",
+    "WF_FFAT_LONG_RUN": "Key_FFAT_GPU: runs of at least n tuples of a key in a batch are folded by a wave instead of a thread (12; profiles/r3_flagship/long_run_threshold.txt)",
     "WF_INHERIT_STREAMS": "0: a GPU replica fused onto its producer keeps its own stream instead of continuing on the producer's (1)",
     "WF_EVENT_BLOCKING": "1: host waits on events sleep instead of spinning",
     "WF_STREAM_REAP": "how often finished stream work is reaped",
