@@ -160,8 +160,8 @@ int main(int argc, char** argv) {
     }
     std::atomic<uint64_t> generated{0}, results{0};
     if (batch_fed) {
-        if (op != "kf_gpu" && op != "wf_gpu" && op != "kff_gpu" && op != "pf_gpu" && op != "wmr_gpu") {
-            std::cerr << "-B needs a GPU operator with a batch path (kf_gpu, wf_gpu, kff_gpu, pf_gpu, wmr_gpu)" << std::endl;
+        if (op != "kf_gpu" && op != "wf_gpu" && op != "kff_gpu" && op != "pf_gpu" && op != "wmr_gpu" && op != "pf_hy" && op != "wmr_hy") {
+            std::cerr << "-B needs a GPU operator with a batch path (kf_gpu, wf_gpu, kff_gpu, pf_gpu, wmr_gpu, pf_hy, wmr_hy)" << std::endl;
             return 2;
         }
         const size_t keys_per_source = std::max<size_t>(1, keys / sources);
@@ -187,13 +187,28 @@ int main(int argc, char** argv) {
         else if (op == "wmr_gpu")  // every window cut into 4 stripes: map per stripe, reduce over the 4 partial results
             oper = WinMapReduceGPU_Builder(SumGPU(), Sum2GPU()).withCBWindows(win, slide).withName(op).withParallelism(4, replicas).withMaxKeys(max_keys)
                        .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
+        else if (op == "pf_hy")  // the reference's form, fed with batches: PLQ on the device, WLQ on the host (results leave as tuples)
+            oper = PaneFarmGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(replicas, 2).withMaxKeys(max_keys)
+                       .withKeyDisjointLanes(disjoint).build_unique();
+        else if (op == "wmr_hy")  // MAP on the device (4 stripes), REDUCE on the host
+            oper = WinMapReduceGPU_Builder(SumGPU(), sum2_nic).withCBWindows(win, slide).withName(op).withParallelism(4, replicas).withMaxKeys(max_keys)
+                       .withKeyDisjointLanes(disjoint).build_unique();
         else
             oper = KeyFFATGPU_Builder(LiftGPU(), CombGPU()).withCBWindows(win, slide).withName(op).withParallelism(replicas).withMaxKeys(max_keys)
                        .withOutputCapacity(out_cap).withKeyDisjointLanes(disjoint).build_unique();
         mp.add(*oper);
-        auto sink = BatchSink_Builder([&results](const result_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
-                        .withName("sink").withParallelism(replicas).build_unique();
-        mp.chain_sink(*sink);
+        std::unique_ptr<Basic_Operator> sink;
+        if (op == "pf_hy" || op == "wmr_hy")
+            sink = Sink_Builder([&results](std::optional<result_t>& r) {
+                       if (r) results.fetch_add(1, std::memory_order_relaxed);
+                   }).withName("sink").withParallelism(1).build_unique();
+        else
+            sink = BatchSink_Builder([&results](const result_t*, size_t n) { results.fetch_add(n, std::memory_order_relaxed); })
+                       .withName("sink").withParallelism(replicas).build_unique();
+        if (op == "pf_hy" || op == "wmr_hy")
+            mp.add_sink(*sink);
+        else
+            mp.chain_sink(*sink);
         graph.run();
         const double elapsed = (current_time_usecs() - t0) / 1e6;
         std::cout << op << " [batch-fed] sources=" << sources << " replicas=" << replicas << " keys=" << keys_per_source * sources << " win=" << win
