@@ -254,7 +254,7 @@ inline bool pool_wait_on_host() {
     return h;
 }
 // WF_COALESCE_TUPLES=n: a GPU replica that finds several small host batches queued uploads them into ONE device batch of at
-// most n tuples (default 131072; 0: never) - the launches of a batch cost the same for 16 Ki tuples as for 128 Ki, so a
+// most n tuples (default 131072, times the number of its producers up to 4; 0: never) - the launches of a batch cost the same for 16 Ki tuples as for 128 Ki, so a
 // replica that has fallen behind catches up with fewer, larger batches, and one that keeps up sees single batches
 inline size_t coalesce_tuples() {
     static const size_t v = [] {

@@ -1275,15 +1275,9 @@ public:
 protected:
     void process_device(gpu::Batch* d) override {
         if (!engine_) {
-            // (the user's output capacity is meant per batch of the operator's configured length: input batches that hold
-            // several of those - small host batches coalesced by a replica that had fallen behind, GPU_Replica::svc_bulk, here
-            // or upstream - get that many times the room, up to the automatic size)
-            size_t out_cap = 2 * d->capacity;
-            if (wcfg_.out_capacity != 0) {
-                const size_t unit = std::max<size_t>(this->cfg_.batch_len, 1);
-                const size_t scale = std::max<size_t>(this->input_scale(), (d->capacity + unit - 1) / unit);
-                out_cap = scale <= 1 ? wcfg_.out_capacity : std::min<size_t>(std::max(out_cap, wcfg_.out_capacity), wcfg_.out_capacity * scale);
-            }
+            // (a user's output capacity grows with input batches that coalesce several of the configured length: GPU_Replica)
+            size_t out_cap = this->scaled_out_capacity(wcfg_.out_capacity, d->capacity);
+            if (out_cap == 0) out_cap = 2 * d->capacity;
             engine_.reset(new gpu::KeyedFFATEngine<tuple_t, result_t, L, C>(lift_, comb_, wcfg_.win_len, wcfg_.slide_len, wcfg_.delay, wcfg_.type,
                                                                             wcfg_.max_keys, d->capacity, out_cap, this->cfg_.gpu_id,
                                                                             this->cfg_.pool_slabs, wcfg_.skip_empty_gaps));

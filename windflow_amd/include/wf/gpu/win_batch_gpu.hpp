@@ -1318,7 +1318,9 @@ protected:
 private:
     void ensure_engine(size_t batch_capacity) {
         if (engine_) return;
-        engine_.reset(new gpu::WinBatchEngine<tuple_t, result_t, F>(func_, p_, opt_, batch_capacity, this->cfg_.gpu_id, this->cfg_.pool_slabs,
+        gpu::WinGPUOptions o = opt_;
+        o.out_capacity = this->scaled_out_capacity(opt_.out_capacity, batch_capacity);  // (coalesced input batches: GPU_Replica)
+        engine_.reset(new gpu::WinBatchEngine<tuple_t, result_t, F>(func_, p_, o, batch_capacity, this->cfg_.gpu_id, this->cfg_.pool_slabs,
                                                                    this->cfg_.scratchpad_size));
     }
     void check_counters(const gpu::WinCounters& c) {
