@@ -28,6 +28,15 @@ RUNTIME_ENV = {
     "WF_WIN_QUIET_RUNS": "0: the non-incremental GPU window engine gathers every run of a batch into the work buffer, also the short ones that fire no window (1: those are appended to the key's carry area in place)",
     "WF_COALESCE_TUPLES": "a GPU replica that finds several small host batches queued uploads them into one device batch of at most n tuples; 0: never (131072)",
     "WF_FFAT_LONG_RUN": "Key_FFAT_GPU: runs of at least n tuples of a key in a batch are folded by a wave instead of a thread (12; profiles/r3_flagship/long_run_threshold.txt)",
+    "WF_DEBUG_EVENTS": "1: every batch release checks that its stream is alive and that slab, event and calling thread belong to the same device (0)",
+    "WF_LDS_LIMIT": "bytes of LDS per workgroup the kernels may plan with (what the device reports: 160 KB on gfx950)",
+    "WF_SORT_SKIP": "0: the keyed engines always sort their batches, even when no key repeats (1)",
+    "WF_SORT_RESCUE": "0: a stream trusted to hold no repeats keeps the six gated sort launches instead of the single rescue launch (1)",
+    "WF_SMALL_SORT": "0: batches of at most 16 Ki pairs behind a gate use the multi-launch radix sort instead of the one-workgroup network (1)",
+    "WF_TS_PRESORT": "(key, timestamp) pre-sort of batches whose runs are out of timestamp order: 0 never, 1 when the device reports disorder, 2 always (1)",
+    "WF_TUPLE_PATH": "1: GPU operators behind CPU producers are fed tuple by tuple (no Batcher), as in the reference (0)",
+    "WF_RCCL_VERBOSE": "1: RcclTransport prints the RCCL version and the path of the loaded library (0)",
+    "WF_ALLOW_STALE_BINARIES": "1: build_cpp falls back to an existing binary when its rebuild fails instead of raising (0)",
     "WF_INHERIT_STREAMS": "0: a GPU replica fused onto its producer keeps its own stream instead of continuing on the producer's (1)",
     "WF_EVENT_BLOCKING": "1: host waits on events sleep instead of spinning",
     "WF_STREAM_REAP": "how often finished stream work is reaped",
