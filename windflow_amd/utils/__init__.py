@@ -35,7 +35,7 @@ RUNTIME_ENV = {
     "WF_SMALL_SORT": "0: batches of at most 16 Ki pairs behind a gate use the multi-launch radix sort instead of the one-workgroup network (1)",
     "WF_TS_PRESORT": "(key, timestamp) pre-sort of batches whose runs are out of timestamp order: 0 never, 1 when the device reports disorder, 2 always (1)",
     "WF_TUPLE_PATH": "1: GPU operators behind CPU producers are fed tuple by tuple (no Batcher), as in the reference (0)",
-    "WF_RCCL_VERBOSE": "1: RcclTransport prints the RCCL version and the path of the loaded library (0)",
+    "WF_RCCL_VERBOSE": "set: RcclTransport prints the RCCL version and the path of the loaded library even under WF_QUIET=1 (it always does otherwise)",
     "WF_ALLOW_STALE_BINARIES": "1: build_cpp falls back to an existing binary when its rebuild fails instead of raising (0)",
     "WF_INHERIT_STREAMS": "0: a GPU replica fused onto its producer keeps its own stream instead of continuing on the producer's (1)",
     "WF_EVENT_BLOCKING": "1: host waits on events sleep instead of spinning",
