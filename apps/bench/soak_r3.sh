@@ -38,6 +38,7 @@ run 100 python3 bench.py --steps 120 --warmup 5 --keys 64 --shared-keys --device
 run 100 python3 bench.py --steps 150 --warmup 5 --parallelism keyby --device-probe-steps 0
 run 100 python3 bench.py --steps 150 --warmup 5 --pipeline ysb
 run 100 python3 bench.py --steps 150 --warmup 5 --pipeline win_seq --keys 1024
+run 100 python3 bench.py --steps 150 --warmup 5 --pipeline win_seq --keys 1
 run 60 apps/bin/bench_win_gpu -o pf_gpu -s 4 -n 4 -k 64 -b 65536 -t 40
 run 60 apps/bin/bench_win_gpu -o wmr_gpu -s 4 -n 4 -k 64 -b 65536 -t 40 -D
 run 60 apps/bin/bench_ops_gpu -o map_stateful -s 14 -n 14 -k 1000 -b 10000 -t 40
