@@ -437,7 +437,12 @@ def test_key_ffat_fuzz(ext, case):
         t, vals = bursty_stream(n, n_keys, seed=1000 + i, gap_every=gap_every, gap_len=gap_len, disorder=disorder)
     else:
         t, vals = make_stream(n, n_keys, seed=1000 + i)
-    res, ctr = ext.key_ffat_run(t, win, slide, delay, tb, max(16, n_keys), batch, 1 << 19, mode)
+    # results per output batch: a time-based key fires a window per slide of TIME, tuples or not (a small slide and long silences
+    # make millions of them; in the worst case one batch fires them all)
+    out_cap = 1 << 19
+    if tb:
+        out_cap = max(out_cap, int(sum(int(t[t[:, 0] == k, 2].max()) // slide + 2 for k in np.unique(t[:, 0]))))
+    res, ctr = ext.key_ffat_run(t, win, slide, delay, tb, max(16, n_keys), batch, out_cap, mode)
     assert ctr["overflow"] == 0 and ctr["table_full"] == 0 and ctr["dropped"] == 0 and ctr["skipped_windows"] == 0
     got = unpack(res)
     assert len(got) == len(res), "duplicate (key, window) results"
