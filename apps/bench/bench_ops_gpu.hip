@@ -168,7 +168,7 @@ int main(int argc, char** argv) {
     size_t sources = 4, replicas = 0, keys = 1 << 14, batch = 1 << 17;
     double seconds = 3.0;
     bool device_source = false;
-    size_t inflight = 6;  // pinned slabs per source: batches that can be queued in front of a replica
+    size_t inflight = 0;  // pinned slabs per source: batches that can be queued in front of a replica (0: 6, or 12 for small batches)
     int c;
     while ((c = getopt(argc, argv, "o:s:n:k:b:t:di:")) != -1) {
         switch (c) {
@@ -229,6 +229,9 @@ int main(int argc, char** argv) {
                   })
                   .build_unique();
     } else {
+        // a replica groups at most half of its producer's slabs (WF_COALESCE_SHARE): small batches get a deeper ring so that a
+        // group still amortises the launches (profiles/r3_small_batch/coalescing_share.txt)
+        if (inflight == 0) inflight = batch < 32768 ? 12 : 6;
         src = BatchSource_Builder(gen).withName("source").withParallelism(sources).withBatch(batch).withInFlightBatches(inflight).build_unique();
     }
     MultiPipe& mp = graph.add_source(*src);

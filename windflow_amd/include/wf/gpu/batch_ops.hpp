@@ -639,7 +639,7 @@ public:
         size_t i = 0;
         while (i < n) {
             gpu::Batch* first = static_cast<gpu::Batch*>(msgs[i]);
-            const size_t room = coalesce_capacity(first->capacity);
+            const size_t room = group_room(first);
             size_t k = 1, tuples = first->host_hdr.count;
             while (i + k < n && !has_token(static_cast<gpu::Batch*>(msgs[i + k - 1]))) {
                 gpu::Batch* next = static_cast<gpu::Batch*>(msgs[i + k]);
@@ -760,6 +760,16 @@ private:
         const size_t lim = gpu::coalesce_tuples() * std::min<size_t>(4, std::max<size_t>(1, this->num_in()));
         if (!this->has_input_rings() || host_capacity == 0 || lim < 2 * host_capacity) return host_capacity;
         return (lim / host_capacity) * host_capacity;
+    }
+    // what one group of svc_bulk may hold: the device slab, and with a single producer no more than its share of the slabs
+    // that producer keeps in flight (gpu::coalesce_share) - the producer needs the others to go on filling
+    size_t group_room(const gpu::Batch* first) const {
+        size_t room = coalesce_capacity(first->capacity);
+        if (this->num_in() <= 1 && first->pool != nullptr && gpu::coalesce_share() > 1) {
+            const size_t share = (first->pool->max_slabs() + gpu::coalesce_share() - 1) / gpu::coalesce_share() * first->capacity;
+            room = std::min(room, std::max(share, gpu::COALESCE_SMALL_GROUP));
+        }
+        return room;
     }
     static bool has_token(const gpu::Batch* b) {
         const uint64_t* r = b->host_hdr.reserved;

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -263,6 +264,18 @@ inline size_t coalesce_tuples() {
     }();
     return v;
 }
+// WF_COALESCE_SHARE=d: a replica with ONE producer groups at most 1/d of the slabs that producer keeps in flight (default 2;
+// 1: all of them) unless the group is small anyway (32 Ki tuples): a group that holds every slab of its producer leaves it
+// nothing to fill meanwhile, and the tail latency pays for the burst (16 Ki batches, 4 in flight: p99 2.6 -> 1.4 ms at the
+// same 1.02 G tuples/s, profiles/r3_small_batch/coalescing_share.txt)
+inline size_t coalesce_share() {
+    static const size_t v = [] {
+        const char* e = std::getenv("WF_COALESCE_SHARE");
+        return e ? std::max<size_t>(1, (size_t)std::atoll(e)) : (size_t)2;
+    }();
+    return v;
+}
+constexpr size_t COALESCE_SMALL_GROUP = 32768;
 // WF_INHERIT_STREAMS=0: a GPU replica fused onto its producer keeps a stream of its own instead of continuing on the producer's
 inline bool inherit_streams() {
     static const bool h = [] {
@@ -465,6 +478,7 @@ public:
     size_t capacity() const { return capacity_; }
     size_t elem_size() const { return elem_size_; }
     size_t allocated() const { return all_.size(); }
+    size_t max_slabs() const { return max_slabs_; }
 
 private:
     Batch* pop() {

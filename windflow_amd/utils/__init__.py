@@ -27,6 +27,7 @@ RUNTIME_ENV = {
     "WF_EDGE_WAIT": "host | device: where a consumer waits for the event of a batch produced by another stream (device)",
     "WF_WIN_QUIET_RUNS": "0: the non-incremental GPU window engine gathers every run of a batch into the work buffer, also the short ones that fire no window (1: those are appended to the key's carry area in place)",
     "WF_COALESCE_TUPLES": "a GPU replica that finds several small host batches queued uploads them into one device batch of at most n tuples; 0: never (131072)",
+    "WF_COALESCE_SHARE": "a GPU replica with one producer groups at most 1/d of the slabs that producer keeps in flight, unless the group is under 32 Ki tuples; 1: all of them (2)",
     "WF_FFAT_LONG_RUN": "Key_FFAT_GPU: runs of at least n tuples of a key in a batch are folded by a wave instead of a thread (12; profiles/r3_flagship/long_run_threshold.txt)",
     "WF_DEBUG_EVENTS": "1: every batch release checks that its stream is alive and that slab, event and calling thread belong to the same device (0)",
     "WF_LDS_LIMIT": "bytes of LDS per workgroup the kernels may plan with (what the device reports: 160 KB on gfx950)",
