@@ -484,7 +484,16 @@ public:
             // every lane carries every key: device KeyBy in front of the replicas (the batches of all sources are packed by replica
             // and merged: a replica receives batches of up to 2 * n_sources / replicas input batches)
             wcfg.lanes_are_key_disjoint = false;
-            n_sinks_ = agg_replicas ? agg_replicas : std::min<size_t>(n_sources, 4);
+            // Few keys mean runs of thousands of tuples per key and batch, which the engine spreads over the whole chip key by key:
+            // several replicas doing that at once only get in each other's way (64 keys, DEFAULT graph: one replica 0.98-1.09 G
+            // tuples/s with p99 7 ms in every run; four replicas 0.97 G / 13 ms or 0.5-0.65 G / 23 ms depending on how their
+            // kernels happened to interleave; 512 keys: 1.01-1.07 G against 0.78-1.09 G - profiles/r3_shared_keys/replicas.md).  From about
+            // a thousand keys on, 3-4 replicas win (1.24-1.33 G against 1.09-1.17 G).
+            n_sinks_ = agg_replicas ? agg_replicas : (n_keys <= 512 && !deterministic) ? 1 : std::min<size_t>(n_sources, 4);
+            // (a DETERMINISTIC graph merges the lanes in front of a single replica, and with them their step punctuations: the
+            // benchmark's step barrier has no count for that case - the run would wait forever)
+            if (deterministic && n_sinks_ == 1 && n_sources > 1)
+                throw std::invalid_argument("WinAggPipeline: shared keys in a DETERMINISTIC graph need at least two aggregation replicas");
             wcfg.max_keys = n_keys / n_sinks_;  // shared: n_keys is the whole key space
             wcfg.max_keys += wcfg.max_keys / 4 + 1024;
             wcfg.out_capacity = std::max<size_t>(2 * n_sources * batch_len / n_sinks_, 2 * batch_len);
