@@ -227,6 +227,33 @@ def test_win_agg_pipeline_end_to_end(ext):
     assert st2["overflow"] == 0 and st2["table_full"] == 0
 
 
+@pytest.mark.parametrize("keys", [64, 700])
+def test_win_agg_pipeline_shared_keys_replica_counts_agree(ext, keys):
+    """Every source emits every key (time-based windows, a delay that covers the lag the sources are allowed): the default plan -
+    ONE replica without a device KeyBy for key spaces of at most 512 keys, four behind the KeyBy above - fires the same windows
+    with the same sums as an explicit two-replica plan.  (bench.py --shared-keys; profiles/r3_shared_keys/replicas.md)"""
+    n_sources, per_source, win, slide, delay = 3, 120_000, 4096, 1024, 40 * 8192
+
+    def run(replicas):
+        pipe = ext.WinAggPipeline(0, n_sources, 8192, keys, win, slide, True, delay, 4, None, replicas, 0, 1.3, True)
+        pipe.step(per_source)
+        pipe.step(per_source)
+        pipe.close()
+        return pipe.stats()
+
+    default, two = run(0), run(2)
+    for st in (default, two):
+        assert st["dropped"] == 0 and st["overflow"] == 0 and st["table_full"] == 0
+    assert default["sink_tuples"] == two["sink_tuples"] > 0
+    assert default["sink_value_sum"] == two["sink_value_sum"]  # (integers in doubles: exact)
+
+
+def test_win_agg_pipeline_refuses_a_single_replica_in_a_deterministic_graph(ext):
+    """the merged lanes carry one step punctuation, not one per source: the benchmark pipeline says so instead of waiting forever"""
+    with pytest.raises(ValueError, match="at least two aggregation replicas"):
+        ext.WinAggPipeline(0, 3, 8192, 64, 4096, 1024, True, 0, 4, None, 1, 0, 1.3, True, True)
+
+
 def test_key_ffat_with_hip_graph_replay(ext, monkeypatch):
     """WF_HIP_GRAPHS=1: the per-batch kernel sequence is captured once per slab pair and replayed."""
     monkeypatch.setenv("WF_HIP_GRAPHS", "1")
