@@ -20,4 +20,4 @@ row "64 keys zipf" 2 --keys 64 --key-dist zipf
 row "64 keys, 64 Ki batches" 2 --keys 64 --batch 65536
 row "64 keys deterministic" 2 --keys 64 --deterministic
 row "1024 keys" 2 --keys 1024
-timeout -k 10 100 python bench.py --steps 2 --warmup 1 --shared-keys --keys 64 --deterministic --agg-replicas 1 --device-probe-steps 0 > $O/guard.json 2> $O/guard.err; echo "deterministic with one replica: exit status $? ($(grep -a -o 'WinAggPipeline: shared keys[^\"]*' $O/guard.err | head -1))" | tee -a $O/one_replica_more.txt
+row "64 keys deterministic, 1 replica" 1 --keys 64 --deterministic --agg-replicas 1

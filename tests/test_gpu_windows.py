@@ -248,10 +248,22 @@ def test_win_agg_pipeline_shared_keys_replica_counts_agree(ext, keys):
     assert default["sink_value_sum"] == two["sink_value_sum"]  # (integers in doubles: exact)
 
 
-def test_win_agg_pipeline_refuses_a_single_replica_in_a_deterministic_graph(ext):
-    """the merged lanes carry one step punctuation, not one per source: the benchmark pipeline says so instead of waiting forever"""
-    with pytest.raises(ValueError, match="at least two aggregation replicas"):
-        ext.WinAggPipeline(0, 3, 8192, 64, 4096, 1024, True, 0, 4, None, 1, 0, 1.3, True, True)
+def test_win_agg_pipeline_shared_keys_single_replica_in_a_deterministic_graph(ext):
+    """DETERMINISTIC graph, count-based windows over shared keys: the lanes are merged in timestamp order in front of the
+    replica(s), so one replica and two fire the same windows with the same sums (and a step ends on ONE merged punctuation)"""
+
+    def run(replicas):
+        pipe = ext.WinAggPipeline(0, 3, 8192, 64, 16, 4, False, 0, 4, None, replicas, 0, 1.3, True, True)
+        pipe.step(60_000)
+        pipe.step(60_000)
+        pipe.close()
+        return pipe.stats()
+
+    one, two = run(1), run(2)
+    for st in (one, two):
+        assert st["dropped"] == 0 and st["overflow"] == 0 and st["table_full"] == 0
+    assert one["sink_tuples"] == two["sink_tuples"] > 0
+    assert one["sink_value_sum"] == two["sink_value_sum"]
 
 
 def test_key_ffat_with_hip_graph_replay(ext, monkeypatch):
